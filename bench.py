@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- batched TOPP-RA throughput on MI355X (driver contract: one JSON line on rank 0).
+
+A "step" is one pass of the hot path (compute_constraint_params + backward controllable-set scan
++ forward parameterization scan, fused) over one batch of synthetic random 7-DoF splines that is
+already resident in HBM.  Workload per GPU: B=65536 trajectories x N=200 gridpoints x 7 DoF,
+velocity + acceleration (Interpolation) constraints, fp64 -- BASELINE.json's headline shape.
+With --gpus N every rank solves its own 65536-trajectory shard (weak scaling; 8 ranks = config 5's
+524288 trajectories) and the step ends with the RCCL gather of sd^2 to rank 0 that the north star
+names.  `value` is whole-job trajectories/s.
+
+  python bench.py                      # 1 GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(d, N, nseg):
+    """Compulsory HBM traffic per trajectory of the fused path with full API outputs
+    (SURVEY.md section 8(d)): inputs coef+breaks+limits+boundary velocities, outputs sd^2, u, K,
+    status."""
+    inp = 8 * (4 * nseg * d + (nseg + 1) + 4 * d + 2)
+    out = 8 * ((N + 1) + N + 2 * (N + 1)) + 4
+    return inp + out
+
+
+def cpu_baseline(data, target_seconds=12.0):
+    """The oracle (C port of the reference's seidel path, bit-exact with it) on the host cores,
+    on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    B = data["coef"].shape[0]
+
+    def run(n):
+        t0 = time.perf_counter()
+        orc.solve_batch(data["coef"][:n], data["breaks"], data["grid"], data["vlim"][:n],
+                        data["alim"][:n], nthreads=cores)
+        return time.perf_counter() - t0
+
+    n0 = min(B, 64 * cores)
+    run(min(B, 8 * cores))  # warm the library / thread pool
+    t = run(n0)
+    n = int(min(B, max(n0, n0 * target_seconds / max(t, 1e-6))))
+    t = run(n)
+    return {"value": n / t, "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "sample": "first %d trajectories of the rank-0 batch, oracle/seidel_oracle.c with OpenMP "
+                      "over %d threads, %.1f s" % (n, cores, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
+    ap.add_argument("--dof", type=int, default=7)
+    ap.add_argument("--gridpoints", type=int, default=200, help="N (stages)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from toppra_amd import batch as tb
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, d, N = args.batch, args.dof, args.gridpoints
+    data = tb.make_synthetic_batch(B, d, N, seed=20240924 + rank)
+    nseg = data["coef"].shape[2]
+    dv = {k: torch.from_numpy(np.ascontiguousarray(data[k])).to(dev)
+          for k in ("coef", "breaks", "grid", "vlim", "alim")}
+
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty((B, N + 1), dtype=torch.float64, device=dev) for _ in range(world)]
+
+    def step():
+        out = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"],
+                             variant=args.variant)
+        if world > 1:
+            dist.gather(out["sd2"], gather_list, dst=0)
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: average launch duration with HIP events on the launch stream
+    kernel_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], out,
+                                     reps=args.kernel_reps, variant=args.variant)
+    ok_frac = float((out["status"] == 0).double().mean().item())
+
+    if rank == 0:
+        bytes_per_traj = algorithmic_bytes(d, N, nseg)
+        achieved = bytes_per_traj * B / (kernel_ms * 1e-3) / 1e9
+        traj_per_s = world * B * args.steps / elapsed
+        line = {
+            "metric": "trajectories/sec (7-DoF N=200 batch; waypoint-LPs/sec = 3N x this)",
+            "value": traj_per_s,
+            "unit": "trajectories/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "batch=%d per GPU, %d-DoF random cubic splines (5 waypoints), N=%d gridpoints, "
+                            "JointVelocity+JointAcceleration(Interpolation), seidel path, fp64" % (B, d, N),
+                "global_batch": world * B, "dof": d, "gridpoints": N,
+                "parallelism": "shard%d+rccl_gather(sd2)" % world if world > 1 else "single",
+                "kernel_variant": args.variant,
+            },
+            "waypoint_lps_per_s": 3 * N * traj_per_s,
+            "ok_fraction": ok_frac,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_trajectory": bytes_per_traj,
+                "note": "fused path is fp64-VALU/divergence bound, not HBM bound (DESIGN.md)",
+            },
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(data)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * toppra_hip.h -- C-ABI of the MI355X-native batched TOPP-RA "seidel" path.
+ *
+ * This is the drop-in boundary: a plain-C shared library (libtoppra_hip.so) with no torch or
+ * Python types in its signatures.  Each entry point names the reference interface it replaces
+ * (paths relative to the reference root, hungpham2511/toppra v0.6.2).  The reference calls its
+ * solver once per stage from Python (3N calls per trajectory); this library takes over at the
+ * *pass* level and adds the batch dimension, so one call solves B independent trajectories.
+ *
+ * Layouts are trajectory-major, C-contiguous, fp64 (int32 for status / active sets):
+ *   coef   [B][4][nseg][d]   scipy CubicSpline.c of each path (interpolator.py:419), highest
+ *                            power first
+ *   breaks [nseg+1]          spline breakpoints (CubicSpline.x); [B][nseg+1] with
+ *                            TPR_BREAKS_PER_TRAJ
+ *   grid   [N+1]             path discretisation; [B][N+1] with TPR_GRID_PER_TRAJ
+ *   vlim   [B][d][2]         JointVelocityConstraint.vlim      (linear_joint_velocity.py:19-28)
+ *   alim   [B][d][2]         JointAccelerationConstraint.alim  (linear_joint_acceleration.py:46-52)
+ *   sd_start, sd_end [B]     boundary path velocities (NULL = 0)
+ *
+ * Buffers belong to the caller.  Pointers are host pointers unless TPR_DEVICE_PTRS is set, in
+ * which case every pointer in tpr_problem/tpr_result is a device pointer on the current device
+ * and the call is asynchronous on `stream` (a hipStream_t passed as void*, NULL = default).
+ *
+ * Numerical failure is data, not an error code, exactly as in the reference: the per-trajectory
+ * status is TPR_STATUS_* and failed outputs are NaN-filled.  The int return value reports API
+ * misuse only (0 = ok, negative = error; text via tpr_last_error()).
+ */
+#ifndef TOPPRA_HIP_H
+#define TOPPRA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPR_MAX_DOF 16 /* rows per LP: nC = 2 + 4*d <= 66 */
+
+/* tpr_problem.flags */
+#define TPR_HAS_VELOCITY 1      /* JointVelocityConstraint present                             */
+#define TPR_HAS_ACCELERATION 2  /* JointAccelerationConstraint present                         */
+#define TPR_ACC_INTERPOLATION 4 /* DiscretizationType.Interpolation (reference default), else Collocation */
+#define TPR_DEVICE_PTRS 8
+#define TPR_BREAKS_PER_TRAJ 16
+#define TPR_GRID_PER_TRAJ 32
+
+/* per-trajectory status == ParameterizationReturnCode (algorithm/algorithm.py:49-62) */
+#define TPR_STATUS_OK 0
+#define TPR_STATUS_FAIL_UNCONTROLLABLE 1
+#define TPR_STATUS_ERR_UNKNOWN 2
+
+/* API error codes */
+#define TPR_E_OK 0
+#define TPR_E_BADARG (-1)
+#define TPR_E_HIP (-2)
+#define TPR_E_UNSUPPORTED (-3)
+
+typedef struct tpr_problem {
+    int32_t B, d, nseg, N;
+    int32_t flags;
+    int32_t variant; /* kernel selection: 0 = auto, 1 = lane-per-trajectory, 2 = rows-across-lanes */
+    const double *coef;
+    const double *breaks;
+    const double *grid;
+    const double *vlim;
+    const double *alim;
+    const double *sd_start;
+    const double *sd_end;
+} tpr_problem;
+
+typedef struct tpr_result {
+    double *sd2;     /* [B][N+1]    x_i = sd_i^2           (may be NULL)                          */
+    double *sd;      /* [B][N+1]    sd_vec = sqrt(x)       (may be NULL)                          */
+    double *u;       /* [B][N]      sdd_vec                (may be NULL)                          */
+    double *K;       /* [B][N+1][2] controllable sets      (REQUIRED: the forward scan reads it)  */
+    int32_t *status; /* [B]                                (may be NULL)                          */
+} tpr_result;
+
+/* Library / device management.  tpr_init selects the HIP device (hipSetDevice) and must succeed
+ * before any other call; it fails (TPR_E_HIP) when no gfx950 device is visible.                 */
+int tpr_init(int device);
+int tpr_device_count(void);
+const char *tpr_last_error(void);
+const char *tpr_version(void);
+
+/* Replaces ReachabilityAlgorithm.compute_parameterization (+ TOPPRA._forward_step) for B
+ * trajectories: algorithm/reachabilitybased/reachability_algorithm.py:240-376,
+ * time_optimal_algorithm.py:55-92, including seidelWrapper.__init__'s
+ * compute_constraint_params (cy_seidel_solverwrapper.pyx:425-531) which is fused in.            */
+int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream);
+
+/* Replaces ReachabilityAlgorithm.compute_controllable_sets(sdmin, sdmax)
+ * (reachability_algorithm.py:166-238).  sdmin/sdmax [B]; K [B][N+1][2].                          */
+int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const double *sdmax,
+                                double *K, void *stream);
+
+/* Replaces ReachabilityAlgorithm.compute_feasible_sets (reachability_algorithm.py:131-164).
+ * X [B][N+1][2].                                                                                 */
+int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream);
+
+/* Replaces Constraint.compute_constraint_params + the dense row build of seidelWrapper.__init__
+ * (linear_joint_velocity.py:43-53, linear_joint_acceleration.py:63-104,
+ * linear_constraint.py:164-190, cy_seidel_solverwrapper.pyx:474-520):
+ *   a,b,c [B][N+1][nC] (rows 0,1 zero), low, high [B][N+1][2], qs, qss [B][N+1][d]
+ * Any output may be NULL.  nC = 2 + (4d | 2d | 0) by flags.                                      */
+int tpr_constraint_params_batch(const tpr_problem *p, double *a, double *b, double *c, double *low,
+                                double *high, double *qs, double *qss, void *stream);
+
+/* Replaces seidelWrapper.solve_stagewise_optim (cy_seidel_solverwrapper.pyx:549-697) for ONE
+ * stage of each of B trajectories (the compatibility entry; 1 LP per call per trajectory).
+ *   stage [B]; g [B][2]; xb [B][4] = x_min, x_max, x_next_min, x_next_max (NaN = absent);
+ *   active [B][4] = active_c_up[2], active_c_down[2] warm-start state, updated in place;
+ *   solve_lp1d: the constructor flag (:425); out [B][2] = [u, x] or NaNs.                        */
+int tpr_solve_stagewise_batch(const tpr_problem *p, const int32_t *stage, const double *g,
+                              const double *xb, int32_t *active, int solve_lp1d, double *out,
+                              void *stream);
+
+/* Replaces solve_lp1d / solve_lp2d (cy_seidel_solverwrapper.pyx:42-87 -> :93-144, :149-390) for n
+ * independent LPs of nrows rows each (the known-answer-test entry).
+ *   lp1d: v [n][2], a,b [n][nrows], low,high [n]
+ *         -> result [n], optval [n], optvar [n], active [n]
+ *   lp2d: v [n][3], a,b,c [n][nrows], low,high [n][2], active_in [n][2]
+ *         -> result [n], optval [n], optvar [n][2], active_out [n][2]                            */
+int tpr_lp1d_batch(int n, int nrows, const double *v, const double *a, const double *b,
+                   const double *low, const double *high, int32_t *result, double *optval,
+                   double *optvar, int32_t *active, void *stream);
+int tpr_lp2d_batch(int n, int nrows, const double *v, const double *a, const double *b,
+                   const double *c, const double *low, const double *high, const int32_t *active_in,
+                   int32_t *result, double *optval, double *optvar, int32_t *active_out,
+                   void *stream);
+
+/* Measurement helper used by bench.py: launches the tpr_solve_batch kernel(s) `reps` times on
+ * `stream` between two hipEvents recorded on that same stream and returns the average
+ * milliseconds per launch (device pointers required).                                            */
+int tpr_solve_batch_timed(const tpr_problem *p, const tpr_result *r, void *stream, int reps,
+                          float *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPPRA_HIP_H */

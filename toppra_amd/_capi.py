@@ -1,0 +1,179 @@
+"""ctypes binding of libtoppra_hip.so (include/toppra_hip.h).
+
+This is the only place the Python host layer touches native code.  There is no CPU fallback:
+if the library is missing or no gfx950 device is visible every compute entry raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtoppra_hip.so")
+
+MAX_DOF = 16
+HAS_VELOCITY = 1
+HAS_ACCELERATION = 2
+ACC_INTERPOLATION = 4
+DEVICE_PTRS = 8
+BREAKS_PER_TRAJ = 16
+GRID_PER_TRAJ = 32
+
+STATUS_OK, STATUS_FAIL_UNCONTROLLABLE, STATUS_ERR_UNKNOWN = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class ToppraHipError(RuntimeError):
+    """The native library is missing, no MI355X is visible, or an API call failed."""
+
+
+class tpr_problem(C.Structure):
+    _fields_ = [("B", C.c_int32), ("d", C.c_int32), ("nseg", C.c_int32), ("N", C.c_int32),
+                ("flags", C.c_int32), ("variant", C.c_int32),
+                ("coef", C.c_void_p), ("breaks", C.c_void_p), ("grid", C.c_void_p),
+                ("vlim", C.c_void_p), ("alim", C.c_void_p),
+                ("sd_start", C.c_void_p), ("sd_end", C.c_void_p)]
+
+
+class tpr_result(C.Structure):
+    _fields_ = [("sd2", C.c_void_p), ("sd", C.c_void_p), ("u", C.c_void_p), ("K", C.c_void_p),
+                ("status", C.c_void_p)]
+
+
+EXPORTS = (
+    "tpr_init", "tpr_device_count", "tpr_last_error", "tpr_version", "tpr_solve_batch",
+    "tpr_controllable_sets_batch", "tpr_feasible_sets_batch", "tpr_constraint_params_batch",
+    "tpr_solve_stagewise_batch", "tpr_lp1d_batch", "tpr_lp2d_batch", "tpr_solve_batch_timed",
+)
+
+_lib = None
+_lock = threading.Lock()
+_inited_device = None
+
+
+def load():
+    """dlopen the library and declare signatures (no GPU needed for this step)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ToppraHipError(
+                "libtoppra_hip.so is not built: run `python -m toppra_amd.build` "
+                "(there is no CPU fallback for the TOPP-RA path)")
+        L = C.CDLL(LIB_PATH)
+        L.tpr_init.restype = C.c_int
+        L.tpr_init.argtypes = [C.c_int]
+        L.tpr_device_count.restype = C.c_int
+        L.tpr_last_error.restype = C.c_char_p
+        L.tpr_version.restype = C.c_char_p
+        P, R, V = C.POINTER(tpr_problem), C.POINTER(tpr_result), C.c_void_p
+        L.tpr_solve_batch.restype = C.c_int
+        L.tpr_solve_batch.argtypes = [P, R, V]
+        L.tpr_solve_batch_timed.restype = C.c_int
+        L.tpr_solve_batch_timed.argtypes = [P, R, V, C.c_int, C.POINTER(C.c_float)]
+        L.tpr_controllable_sets_batch.restype = C.c_int
+        L.tpr_controllable_sets_batch.argtypes = [P, V, V, V, V]
+        L.tpr_feasible_sets_batch.restype = C.c_int
+        L.tpr_feasible_sets_batch.argtypes = [P, V, V]
+        L.tpr_constraint_params_batch.restype = C.c_int
+        L.tpr_constraint_params_batch.argtypes = [P, V, V, V, V, V, V, V, V]
+        L.tpr_solve_stagewise_batch.restype = C.c_int
+        L.tpr_solve_stagewise_batch.argtypes = [P, V, V, V, V, C.c_int, V, V]
+        L.tpr_lp1d_batch.restype = C.c_int
+        L.tpr_lp1d_batch.argtypes = [C.c_int, C.c_int] + [V] * 10
+        L.tpr_lp2d_batch.restype = C.c_int
+        L.tpr_lp2d_batch.argtypes = [C.c_int, C.c_int] + [V] * 12
+        _lib = L
+        return _lib
+
+
+def last_error():
+    return load().tpr_last_error().decode()
+
+
+def check(rc):
+    if rc != 0:
+        raise ToppraHipError("libtoppra_hip: %s (code %d)" % (last_error(), rc))
+
+
+def init(device=None):
+    """Select the HIP device; raises ToppraHipError when no gfx950 device is usable."""
+    global _inited_device
+    L = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if _inited_device is None else _inited_device
+    if _inited_device == device:
+        return device
+    check(L.tpr_init(int(device)))
+    _inited_device = device
+    return device
+
+
+def device_count():
+    return load().tpr_device_count()
+
+
+# --------------------------------------------------------------------------------------------
+# argument marshalling: numpy (host) or torch CUDA tensors (device, zero-copy)
+
+def is_torch_cuda(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and x.is_cuda
+
+
+def f64(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()
+
+
+def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
+                 variant=0, keep=None):
+    """Build a tpr_problem from arrays (all numpy or all torch-CUDA).  `keep` collects the
+    converted arrays so they outlive the call."""
+    dev = is_torch_cuda(coef)
+    conv = (lambda x: x.contiguous()) if dev else f64
+    keep = keep if keep is not None else []
+    coef = conv(coef)
+    breaks = conv(breaks)
+    grid = conv(grid)
+    if coef.ndim != 4 or coef.shape[1] != 4:
+        raise ValueError("coef must have shape [B, 4, nseg, d]")
+    B, _, nseg, d = (int(s) for s in coef.shape)
+    N = int(grid.shape[-1]) - 1
+    flags = DEVICE_PTRS if dev else 0
+    if breaks.ndim == 2:
+        flags |= BREAKS_PER_TRAJ
+    if grid.ndim == 2:
+        flags |= GRID_PER_TRAJ
+    if int(breaks.shape[-1]) != nseg + 1:
+        raise ValueError("breaks must have nseg+1 entries")
+    p = tpr_problem(B=B, d=d, nseg=nseg, N=N, flags=0, variant=int(variant))
+    keep += [coef, breaks, grid]
+    p.coef, p.breaks, p.grid = ptr(coef), ptr(breaks), ptr(grid)
+    for name, arr, flag in (("vlim", vlim, HAS_VELOCITY), ("alim", alim, HAS_ACCELERATION)):
+        if arr is not None:
+            arr = conv(arr)
+            if tuple(arr.shape) != (B, d, 2):
+                raise ValueError("%s must have shape [B, d, 2]" % name)
+            keep.append(arr)
+            setattr(p, name, ptr(arr))
+            flags |= flag
+    if alim is not None and interpolation:
+        flags |= ACC_INTERPOLATION
+    for name, arr in (("sd_start", sd_start), ("sd_end", sd_end)):
+        if arr is not None:
+            arr = conv(arr)
+            keep.append(arr)
+            setattr(p, name, ptr(arr))
+    p.flags = flags
+    return p, keep

@@ -1,0 +1,150 @@
+"""Batched TOPP-RA entry points over the C-ABI (numpy host arrays or torch-ROCm device tensors).
+
+These are the array-level calls underneath the drop-in classes in :mod:`toppra_amd.algorithm`:
+one call = B independent trajectories, each solved exactly as the reference's
+``TOPPRA(..., solver_wrapper="seidel")`` would (reachability_algorithm.py:166-376).
+
+With numpy inputs the library stages host<->device copies itself; with torch CUDA tensors the
+device pointers are passed through and the kernels run on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+__all__ = ["solve_batch", "controllable_sets_batch", "feasible_sets_batch",
+           "constraint_params_batch", "make_synthetic_batch", "spline_coefficients",
+           "solve_batch_timed"]
+
+
+def _stream_ptr(like):
+    if _capi.is_torch_cuda(like):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(like.device).cuda_stream)
+    return None
+
+
+def _empty(like, shape, dtype="f64"):
+    if _capi.is_torch_cuda(like):
+        import torch
+        return torch.empty(shape, device=like.device,
+                           dtype=torch.float64 if dtype == "f64" else torch.int32)
+    return np.empty(shape, dtype=np.float64 if dtype == "f64" else np.int32)
+
+
+def _prepare(coef):
+    if _capi.is_torch_cuda(coef):
+        dev = coef.device.index if coef.device.index is not None else 0
+        _capi.init(dev)
+    else:
+        _capi.init()
+
+
+def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
+                want_sd=False, variant=0):
+    """compute_parameterization for B trajectories.
+
+    Returns dict(sd2[B,N+1], u[B,N], K[B,N+1,2], status[B] (+ sd[B,N+1] if want_sd)); failed
+    trajectories are NaN-filled with status 1 (FailUncontrollable) or 2 (ErrUnknown)."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
+                                 variant)
+    B, N = p.B, p.N
+    out = {"sd2": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)),
+           "K": _empty(coef, (B, N + 1, 2)), "status": _empty(coef, (B,), "i32")}
+    if want_sd:
+        out["sd"] = _empty(coef, (B, N + 1))
+    r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out["u"]),
+                         K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
+    _capi.check(_capi.load().tpr_solve_batch(C.byref(p), C.byref(r), _stream_ptr(coef)))
+    return out
+
+
+def solve_batch_timed(coef, breaks, grid, vlim, alim, out, reps, sd_start=None, sd_end=None,
+                      interpolation=True, variant=0):
+    """bench.py helper: `reps` launches between two hipEvents on torch's current stream.
+    Returns average ms per launch.  `out` is a dict from a previous solve_batch (device)."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
+                                 variant)
+    r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out["u"]),
+                         K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
+    ms = C.c_float(0)
+    _capi.check(_capi.load().tpr_solve_batch_timed(C.byref(p), C.byref(r), _stream_ptr(coef), int(reps),
+                                                   C.byref(ms)))
+    return float(ms.value)
+
+
+def controllable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpolation=True):
+    """compute_controllable_sets(sdmin, sdmax) for B trajectories -> K[B,N+1,2]."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation)
+    dev = _capi.is_torch_cuda(coef)
+    conv = (lambda x: x.contiguous()) if dev else _capi.f64
+    sdmin, sdmax = conv(sdmin), conv(sdmax)
+    K = _empty(coef, (p.B, p.N + 1, 2))
+    _capi.check(_capi.load().tpr_controllable_sets_batch(C.byref(p), _capi.ptr(sdmin), _capi.ptr(sdmax),
+                                                         _capi.ptr(K), _stream_ptr(coef)))
+    return K
+
+
+def feasible_sets_batch(coef, breaks, grid, vlim, alim, interpolation=True):
+    """compute_feasible_sets for B trajectories -> X[B,N+1,2]."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation)
+    X = _empty(coef, (p.B, p.N + 1, 2))
+    _capi.check(_capi.load().tpr_feasible_sets_batch(C.byref(p), _capi.ptr(X), _stream_ptr(coef)))
+    return X
+
+
+def constraint_params_batch(coef, breaks, grid, vlim, alim, interpolation=True):
+    """compute_constraint_params + seidelWrapper row build for B trajectories.
+
+    Returns dict(a,b,c [B,N+1,nC], low, high [B,N+1,2], qs, qss [B,N+1,d])."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation)
+    nC = 2 + ((4 if interpolation else 2) * p.d if alim is not None else 0)
+    B, N, d = p.B, p.N, p.d
+    out = {k: _empty(coef, (B, N + 1, nC)) for k in ("a", "b", "c")}
+    out.update({k: _empty(coef, (B, N + 1, 2)) for k in ("low", "high")})
+    out.update({k: _empty(coef, (B, N + 1, d)) for k in ("qs", "qss")})
+    _capi.check(_capi.load().tpr_constraint_params_batch(
+        C.byref(p), *[_capi.ptr(out[k]) for k in ("a", "b", "c", "low", "high", "qs", "qss")],
+        _stream_ptr(coef)))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# host-side input preparation (outside the hot path)
+
+def spline_coefficients(knots, waypoints, bc_type="not-a-knot"):
+    """Batched cubic-spline fit on the host: waypoints [B, m, d] -> coef [B, 4, m-1, d].
+
+    One scipy ``CubicSpline`` call over trailing axes; the coefficients are bitwise identical to
+    the per-trajectory ``SplineInterpolator(knots, waypoints[b]).cspl.c`` of the reference
+    (interpolator.py:419)."""
+    from scipy.interpolate import CubicSpline
+    way = np.asarray(waypoints, dtype=np.float64)
+    B, m, d = way.shape
+    cs = CubicSpline(np.asarray(knots, dtype=np.float64), way.transpose(1, 0, 2), bc_type=bc_type)
+    # cs.c: [4, m-1, B, d] -> [B, 4, m-1, d]
+    return np.ascontiguousarray(cs.c.transpose(2, 0, 1, 3)), np.asarray(cs.x, dtype=np.float64)
+
+
+def make_synthetic_batch(B, d, N, seed=20240924, n_waypoints=5):
+    """The benchmark's synthetic random-spline batch, following
+    examples/plot_kinematics.py:22-33: N(0,1) waypoints on linspace(0,1,5), symmetric limits
+    vlim = 10+20 U, alim = 10+2 U, uniform grid, rest-to-rest."""
+    rng = np.random.default_rng(seed)
+    way = rng.standard_normal((B, n_waypoints, d))
+    vmax = 10 + 20 * rng.random((B, d))
+    amax = 10 + 2 * rng.random((B, d))
+    knots = np.linspace(0, 1, n_waypoints)
+    coef, breaks = spline_coefficients(knots, way)
+    return {
+        "coef": coef, "breaks": breaks, "grid": np.linspace(0, 1, N + 1),
+        "vlim": np.ascontiguousarray(np.stack([-vmax, vmax], axis=-1)),
+        "alim": np.ascontiguousarray(np.stack([-amax, amax], axis=-1)),
+        "waypoints": way, "knots": knots,
+    }

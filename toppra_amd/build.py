@@ -1,0 +1,54 @@
+"""Build libtoppra_hip.so (the HIP kernels + C-ABI) in-tree for gfx950.
+
+``python -m toppra_amd.build`` or ``toppra_amd.build.build()``.  hipcc cross-compiles without a
+GPU, so this also runs in the CPU-only build container.  ``-ffp-contract=off`` is mandatory: the
+parity target is the reference's FMA-free x86-64 arithmetic (see csrc/tpr_device.hpp).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtoppra_hip.so")
+SOURCES = ["tpr_kernels.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libtoppra_hip.so)")
+
+
+def deps():
+    out = []
+    for name in os.listdir(CSRC):
+        if name.endswith((".hip", ".hpp", ".inc", ".h")):
+            out.append(os.path.join(CSRC, name))
+    out.append(os.path.join(HERE, "..", "include", "toppra_hip.h"))
+    return out
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in deps())
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

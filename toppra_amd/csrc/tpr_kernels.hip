@@ -1,0 +1,312 @@
+// tpr_kernels.hip -- libtoppra_hip.so: HIP kernels + the C-ABI of include/toppra_hip.h (gfx950).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
+// -ffp-contract=off is a correctness flag, not a tuning knob: see tpr_device.hpp.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/toppra_hip.h"
+#include "tpr_device.hpp"
+#include "tpr_lane.hip.inc"
+
+namespace {
+
+thread_local std::string g_err;
+int g_device = -1;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(TPR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+// Host<->device staging for callers that hand over host buffers.  With TPR_DEVICE_PTRS every
+// pointer passes through untouched and nothing here allocates.
+struct Staging {
+    bool device_ptrs;
+    hipStream_t stream;
+    std::vector<void *> owned;
+    struct Out { void *host; void *dev; size_t bytes; };
+    std::vector<Out> outs;
+    hipError_t err = hipSuccess;
+
+    Staging(bool dev, hipStream_t s) : device_ptrs(dev), stream(s) {}
+    ~Staging() {
+        for (void *p : owned) (void)hipFree(p);
+    }
+    template <class T>
+    const T *in(const T *p, size_t count) {
+        if (!p || device_ptrs || count == 0) return p;
+        void *d = nullptr;
+        if (err == hipSuccess) err = hipMalloc(&d, count * sizeof(T));
+        if (err != hipSuccess) return nullptr;
+        owned.push_back(d);
+        err = hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, stream);
+        return static_cast<const T *>(d);
+    }
+    template <class T>
+    T *out(T *p, size_t count, bool copy_in = false) {
+        if (!p || device_ptrs || count == 0) return p;
+        void *d = nullptr;
+        if (err == hipSuccess) err = hipMalloc(&d, count * sizeof(T));
+        if (err != hipSuccess) return nullptr;
+        owned.push_back(d);
+        if (copy_in) err = hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, stream);
+        outs.push_back({p, d, count * sizeof(T)});
+        return static_cast<T *>(d);
+    }
+    hipError_t finish() {
+        if (err != hipSuccess) return err;
+        if (device_ptrs) return hipGetLastError();
+        for (auto &o : outs) {
+            err = hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream);
+            if (err != hipSuccess) return err;
+        }
+        return hipStreamSynchronize(stream);
+    }
+};
+
+int check_problem(const tpr_problem *p) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (!p) return fail(TPR_E_BADARG, "null problem");
+    if (p->B < 0 || p->N < 1 || p->nseg < 1) return fail(TPR_E_BADARG, "need B >= 0, N >= 1, nseg >= 1");
+    if (p->d < 1 || p->d > TPR_MAX_DOF) return fail(TPR_E_UNSUPPORTED, "dof must be in [1, TPR_MAX_DOF]");
+    if (!p->coef || !p->breaks || !p->grid) return fail(TPR_E_BADARG, "coef/breaks/grid are required");
+    if ((p->flags & TPR_HAS_VELOCITY) && !p->vlim) return fail(TPR_E_BADARG, "TPR_HAS_VELOCITY without vlim");
+    if ((p->flags & TPR_HAS_ACCELERATION) && !p->alim) return fail(TPR_E_BADARG, "TPR_HAS_ACCELERATION without alim");
+    return TPR_E_OK;
+}
+
+int rows_per_lp(const tpr_problem *p) {
+    return 2 + ((p->flags & TPR_HAS_ACCELERATION) ? ((p->flags & TPR_ACC_INTERPOLATION) ? 4 : 2) * p->d : 0);
+}
+
+// Stage the inputs of a problem; returns the kernel argument block.
+tpr::BatchArgs stage_problem(const tpr_problem *p, Staging &S) {
+    tpr::BatchArgs A{};
+    const size_t B = (size_t)p->B, d = (size_t)p->d, nseg = (size_t)p->nseg, N = (size_t)p->N;
+    A.B = p->B; A.d = p->d; A.nseg = p->nseg; A.N = p->N; A.flags = p->flags;
+    A.coef = S.in(p->coef, B * 4 * nseg * d);
+    A.breaks = S.in(p->breaks, ((p->flags & TPR_BREAKS_PER_TRAJ) ? B : 1) * (nseg + 1));
+    A.grid = S.in(p->grid, ((p->flags & TPR_GRID_PER_TRAJ) ? B : 1) * (N + 1));
+    A.vlim = S.in(p->vlim, B * d * 2);
+    A.alim = S.in(p->alim, B * d * 2);
+    A.sd_start = S.in(p->sd_start, B);
+    A.sd_end = S.in(p->sd_end, B);
+    return A;
+}
+
+int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
+    if (A.B == 0) return TPR_E_OK;
+    const int variant = p->variant == 0 ? 1 : p->variant;
+    switch (variant) {
+        case 1: {
+            const int block = 64;
+            hipLaunchKernelGGL(tpr::lane_solve_kernel, dim3((A.B + block - 1) / block), dim3(block), 0,
+                               stream, A);
+            return TPR_E_OK;
+        }
+        default:
+            return fail(TPR_E_UNSUPPORTED, "unknown kernel variant");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tpr_last_error(void) { return g_err.c_str(); }
+
+const char *tpr_version(void) { return "toppra_hip 0.1 (gfx950)"; }
+
+int tpr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tpr_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(TPR_E_HIP, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(TPR_E_BADARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(TPR_E_UNSUPPORTED, std::string("this library is built for gfx950 only, found ") + prop.gcnArchName);
+    g_device = device;
+    return TPR_E_OK;
+}
+
+int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream_) {
+    if (int rc = check_problem(p)) return rc;
+    if (!r || !r->K) return fail(TPR_E_BADARG, "result.K is required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::BatchArgs A = stage_problem(p, S);
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    A.sd2 = S.out(r->sd2, B * (N + 1));
+    A.sd = S.out(r->sd, B * (N + 1));
+    A.u = S.out(r->u, B * N);
+    A.K = S.out(r->K, B * (N + 1) * 2);
+    A.status = S.out(r->status, B);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (int rc = launch_solve(p, A, stream)) return rc;
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_solve_batch_timed(const tpr_problem *p, const tpr_result *r, void *stream_, int reps,
+                          float *ms_per_launch) {
+    if (int rc = check_problem(p)) return rc;
+    if (!(p->flags & TPR_DEVICE_PTRS)) return fail(TPR_E_BADARG, "timed entry needs TPR_DEVICE_PTRS");
+    if (!r || !r->K || reps < 1 || !ms_per_launch) return fail(TPR_E_BADARG, "bad timed arguments");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(true, stream);
+    tpr::BatchArgs A = stage_problem(p, S);
+    A.sd2 = r->sd2; A.sd = r->sd; A.u = r->u; A.K = r->K; A.status = r->status;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, stream));
+    for (int i = 0; i < reps; ++i)
+        if (int rc = launch_solve(p, A, stream)) return rc;
+    HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIP_TRY(hipGetLastError());
+    *ms_per_launch = ms / (float)reps;
+    return TPR_E_OK;
+}
+
+int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const double *sdmax,
+                                double *K, void *stream_) {
+    if (int rc = check_problem(p)) return rc;
+    if (!sdmin || !sdmax || !K) return fail(TPR_E_BADARG, "sdmin/sdmax/K are required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::BatchArgs A = stage_problem(p, S);
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    const double *dmin = S.in(sdmin, B), *dmax = S.in(sdmax, B);
+    A.K = S.out(K, B * (N + 1) * 2);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (A.B > 0)
+        hipLaunchKernelGGL(tpr::lane_controllable_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A,
+                           dmin, dmax);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
+    if (int rc = check_problem(p)) return rc;
+    if (!X) return fail(TPR_E_BADARG, "X is required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::BatchArgs A = stage_problem(p, S);
+    double *dX = S.out(X, (size_t)p->B * (p->N + 1) * 2);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (A.B > 0)
+        hipLaunchKernelGGL(tpr::lane_feasible_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dX);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_constraint_params_batch(const tpr_problem *p, double *a, double *b, double *c, double *low,
+                                double *high, double *qs, double *qss, void *stream_) {
+    if (int rc = check_problem(p)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::BatchArgs A = stage_problem(p, S);
+    const size_t pts = (size_t)p->B * (p->N + 1), nC = (size_t)rows_per_lp(p);
+    double *da = S.out(a, pts * nC), *db = S.out(b, pts * nC), *dc = S.out(c, pts * nC);
+    double *dlow = S.out(low, pts * 2), *dhigh = S.out(high, pts * 2);
+    double *dqs = S.out(qs, pts * p->d), *dqss = S.out(qss, pts * p->d);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (pts > 0)
+        hipLaunchKernelGGL(tpr::params_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, stream, A,
+                           da, db, dc, dlow, dhigh, dqs, dqss);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_solve_stagewise_batch(const tpr_problem *p, const int32_t *stage, const double *g,
+                              const double *xb, int32_t *active, int solve_lp1d, double *out,
+                              void *stream_) {
+    if (int rc = check_problem(p)) return rc;
+    if (!stage || !g || !xb || !active || !out) return fail(TPR_E_BADARG, "null stagewise argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::BatchArgs A = stage_problem(p, S);
+    const size_t B = (size_t)p->B;
+    const int32_t *dstage = S.in(stage, B);
+    const double *dg = S.in(g, B * 2), *dxb = S.in(xb, B * 4);
+    int32_t *dact = S.out(active, B * 4, true);
+    double *dout = S.out(out, B * 2);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (A.B > 0)
+        hipLaunchKernelGGL(tpr::lane_stagewise_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dstage,
+                           dg, dxb, dact, solve_lp1d, dout);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_lp1d_batch(int n, int nrows, const double *v, const double *a, const double *b,
+                   const double *low, const double *high, int32_t *result, double *optval,
+                   double *optvar, int32_t *active, void *stream_) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (n < 0 || nrows < 0 || !v || !low || !high || !result || !optval || !optvar || !active)
+        return fail(TPR_E_BADARG, "bad lp1d arguments");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(false, stream);
+    const size_t nn = (size_t)n, rows = nn * (size_t)nrows;
+    const double *dv = S.in(v, nn * 2), *da = S.in(a, rows), *db = S.in(b, rows);
+    const double *dlow = S.in(low, nn), *dhigh = S.in(high, nn);
+    int32_t *dres = S.out(result, nn), *dact = S.out(active, nn);
+    double *dval = S.out(optval, nn), *dvar = S.out(optvar, nn);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (n > 0)
+        hipLaunchKernelGGL(tpr::lp1d_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, nrows, dv, da, db,
+                           dlow, dhigh, dres, dval, dvar, dact);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_lp2d_batch(int n, int nrows, const double *v, const double *a, const double *b,
+                   const double *c, const double *low, const double *high, const int32_t *active_in,
+                   int32_t *result, double *optval, double *optvar, int32_t *active_out,
+                   void *stream_) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (n < 0 || nrows < 0 || nrows > tpr::kKatMaxRows || !v || !low || !high || !active_in || !result ||
+        !optval || !optvar || !active_out)
+        return fail(TPR_E_BADARG, "bad lp2d arguments (nrows <= 128)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(false, stream);
+    const size_t nn = (size_t)n, rows = nn * (size_t)nrows;
+    const double *dv = S.in(v, nn * 3), *da = S.in(a, rows), *db = S.in(b, rows), *dc = S.in(c, rows);
+    const double *dlow = S.in(low, nn * 2), *dhigh = S.in(high, nn * 2);
+    const int32_t *dain = S.in(active_in, nn * 2);
+    int32_t *dres = S.out(result, nn), *daout = S.out(active_out, nn * 2);
+    double *dval = S.out(optval, nn), *dvar = S.out(optvar, nn * 2);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (n > 0)
+        hipLaunchKernelGGL(tpr::lp2d_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, nrows, dv, da, db,
+                           dc, dlow, dhigh, dain, dres, dval, dvar, daout);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+}  // extern "C"
