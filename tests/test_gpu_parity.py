@@ -25,21 +25,26 @@ def _compare(got, ref, exact=True):
             assert np.array_equal(g, r, equal_nan=True), (key, "not bit-exact, max dev %g" % dev)
 
 
-@pytest.mark.parametrize("B,d,N", [(256, 7, 200), (64, 6, 500), (130, 3, 50), (65, 1, 20)])
-def test_solve_batch_matches_oracle(gpu, oracle, B, d, N):
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("B,d,N", [(256, 7, 200), (64, 6, 500), (130, 3, 50), (65, 1, 20), (97, 8, 64),
+                                   (40, 2, 33), (33, 4, 70), (50, 5, 101)])
+def test_solve_batch_matches_oracle(gpu, oracle, B, d, N, variant):
     data = batch.make_synthetic_batch(B, d, N, seed=1234 + d)
-    got = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    got = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"],
+                            variant=variant)
     ref = oracle.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
     assert (ref["status"] == 0).mean() > 0.9
     _compare(got, ref)
 
 
-def test_nonzero_boundary_velocities(gpu, oracle):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_nonzero_boundary_velocities(gpu, oracle, variant):
     data = batch.make_synthetic_batch(128, 7, 100, seed=7)
     rng = np.random.default_rng(5)
     sd0, sd1 = 0.5 * rng.random(128), 0.5 * rng.random(128)
     sd0[::7] = 5.0  # some uncontrollable starts
-    got = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], sd0, sd1)
+    got = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], sd0, sd1,
+                            variant=variant)
     ref = oracle.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], sd0, sd1)
     assert set(np.unique(ref["status"])) >= {0, 1}
     _compare(got, ref)

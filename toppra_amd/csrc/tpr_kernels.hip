@@ -12,6 +12,7 @@
 #include "../../include/toppra_hip.h"
 #include "tpr_device.hpp"
 #include "tpr_lane.hip.inc"
+#include "tpr_group.hip.inc"
 
 namespace {
 
@@ -106,10 +107,42 @@ tpr::BatchArgs stage_problem(const tpr_problem *p, Staging &S) {
     return A;
 }
 
+template <int D, int L>
+void launch_group(const tpr::BatchArgs &A, hipStream_t stream) {
+    tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
+                     A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
+    constexpr int groups = 256 / L;
+    const size_t lds = (size_t)groups * 3 * A.nseg * D * sizeof(double);
+    hipLaunchKernelGGL((tpr::group_solve_kernel<D, L>), dim3((A.B + groups - 1) / groups), dim3(256), lds,
+                       stream, G);
+}
+
+// The rows-across-lanes kernels cover the reference's default constraint set (acceleration with
+// Interpolation, velocity optional) for d <= 8 and spline tables that fit the LDS staging area.
+bool group_supported(const tpr::BatchArgs &A) {
+    const int need = TPR_HAS_ACCELERATION | TPR_ACC_INTERPOLATION;
+    return (A.flags & need) == need && A.d >= 1 && A.d <= 8 && (size_t)A.nseg * A.d * 3 * 8 * 32 <= 64 * 1024;
+}
+
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
     if (A.B == 0) return TPR_E_OK;
-    const int variant = p->variant == 0 ? 1 : p->variant;
+    int variant = p->variant;
+    if (variant == 0) variant = group_supported(A) ? 2 : 1;
     switch (variant) {
+        case 2: {
+            if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 2 needs acceleration+interpolation, d <= 8");
+            switch (A.d) {
+                case 1: launch_group<1, 8>(A, stream); break;
+                case 2: launch_group<2, 8>(A, stream); break;
+                case 3: launch_group<3, 8>(A, stream); break;
+                case 4: launch_group<4, 8>(A, stream); break;
+                case 5: launch_group<5, 8>(A, stream); break;
+                case 6: launch_group<6, 8>(A, stream); break;
+                case 7: launch_group<7, 8>(A, stream); break;
+                case 8: launch_group<8, 8>(A, stream); break;
+            }
+            return TPR_E_OK;
+        }
         case 1: {
             const int block = 64;
             hipLaunchKernelGGL(tpr::lane_solve_kernel, dim3((A.B + block - 1) / block), dim3(block), 0,
