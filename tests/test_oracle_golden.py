@@ -1,0 +1,81 @@
+"""The CPU oracle against outputs of the real reference (tests/golden, tools/make_golden.py):
+bit-exact, including NaN patterns and return codes.  This pins the oracle on machines where the
+reference itself is not importable (the GPU box)."""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_same, batch_fixtures, fixture_problem, golden
+
+
+@pytest.mark.parametrize("name", batch_fixtures())
+def test_batch_fixture(oracle, name):
+    fx = golden(name)
+    coef, breaks, grid, vlim, alim, sd0, sd1, interp = fixture_problem(fx)
+    flags = (oracle.FLAG_VEL if vlim is not None else 0) | oracle.FLAG_ACC | (oracle.FLAG_INTERP if interp else 0)
+    got = oracle.solve_batch(coef, breaks, grid, vlim, alim, sd0, sd1, flags=flags)
+    assert np.array_equal(got["status"], fx["status"])
+    assert_same(got["K"], fx["K"], "K")
+    assert_same(np.sqrt(got["sd2"]), fx["sd"], "sd")
+    assert_same(got["u"], fx["u"], "u")
+    if "X" in fx:
+        for b in range(coef.shape[0]):
+            w = oracle.Wrapper(coef[b], breaks, grid, None if vlim is None else vlim[b], alim[b], flags=flags)
+            assert_same(w.compute_feasible_sets(), fx["X"][b], "X[%d]" % b)
+
+
+@pytest.mark.parametrize("tag", ["n100", "auto"])
+def test_example_kinematics(oracle, tag):
+    fx = golden("example_kinematics_seed9")
+    grid = fx[tag + "_grid"]
+    w = oracle.Wrapper(fx["coef"][0], fx["breaks"], grid, fx["vlim"][0], fx["alim"][0])
+    st, sdd, sd, xs, K = w.compute_parameterization(0.0, 0.0)
+    assert st == int(fx[tag + "_status"]) == 0
+    assert_same(K, fx[tag + "_K"], "K")
+    assert_same(sd, fx[tag + "_sd"], "sd")
+    assert_same(sdd, fx[tag + "_u"], "u")
+    w2 = oracle.Wrapper(fx["coef"][0], fx["breaks"], grid, fx["vlim"][0], fx["alim"][0])
+    assert_same(w2.compute_feasible_sets(), fx[tag + "_X"], "X")
+    # constraint parameters: path derivatives, velocity bound, interpolated acceleration rows
+    d = fx["coef"].shape[3]
+    qs = np.array([oracle.path_eval(fx["coef"][0], fx["breaks"], s)[0] for s in grid])
+    qss = np.array([oracle.path_eval(fx["coef"][0], fx["breaks"], s)[1] for s in grid])
+    assert_same(qs, fx[tag + "_qs"], "qs")
+    assert_same(qss, fx[tag + "_qss"], "qss")
+    xb = np.array([oracle.velocity_xbound(q, fx["vlim"][0]) for q in qs])
+    assert_same(xb, fx[tag + "_xbound"], "xbound")
+    a, b = w.a_arr, w.b_arr
+    assert_same(a[:, np.r_[2:2 + d, 2 + 2 * d:2 + 3 * d]], fx[tag + "_acc_a"], "a_intp")
+    assert_same(b[:, np.r_[2:2 + d, 2 + 2 * d:2 + 3 * d]], fx[tag + "_acc_b"], "b_intp")
+    # wrapper rows = F a, F b, F c - g
+    F, g = fx[tag + "_acc_F"], fx[tag + "_acc_g"]
+    assert_same(a[:, 2:], fx[tag + "_acc_a"] @ F.T, "F a")
+    assert_same(w.c_arr[:, 2:], fx[tag + "_acc_c"] @ F.T - g, "F c - g")
+
+
+@pytest.mark.parametrize("lp1d", [0, 1])
+def test_stagewise_sequence(oracle, lp1d):
+    """solve_stagewise_optim with the reference's stateful warm start, same call sequence."""
+    fx = golden("example_kinematics_seed9")
+    w = oracle.Wrapper(fx["coef"][0], fx["breaks"], fx["n100_grid"], fx["vlim"][0], fx["alim"][0],
+                       solve_lp1d=lp1d)
+    q, r = fx["stagewise_q_lp1d%d" % lp1d], fx["stagewise_r_lp1d%d" % lp1d]
+    assert np.isnan(r).any() and np.isfinite(r).any()
+    for row, want in zip(q, r):
+        got = w.solve_stagewise_optim(int(row[0]), None, row[1:3], *row[3:7])
+        assert_same(got, want, "stagewise")
+
+
+def test_random_lps(oracle):
+    fx = golden("random_lps")
+    for t in range(fx["v"].shape[0]):
+        res, val, var, ac = oracle.lp2d(fx["v"][t], fx["a"][t], fx["b"][t], fx["c"][t], fx["low"][t],
+                                        fx["high"][t], fx["active_in"][t])
+        assert res == fx["result"][t]
+        if res:
+            assert val == fx["optval"][t] and list(var) == list(fx["optvar"][t])
+            assert list(ac) == list(fx["active_out"][t])
+    for t in range(fx["v1"].shape[0]):
+        res, val, var, ac = oracle.lp1d(fx["v1"][t], fx["a1"][t], fx["b1"][t], fx["low1"][t], fx["high1"][t])
+        assert res == fx["result1"][t]
+        if res:
+            assert val == fx["optval1"][t] and var == fx["optvar1"][t] and ac == fx["active1"][t]

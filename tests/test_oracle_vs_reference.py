@@ -1,0 +1,82 @@
+"""Live pinning of the CPU oracle against the REAL reference (build container only: needs
+/root/reference; skipped on the GPU box).  Fresh seeds, bit-exact."""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_same
+
+pytestmark = pytest.mark.reference
+
+
+def _problem(rng, d, nway=5):
+    way = rng.standard_normal((nway, d))
+    vmax = 10 + 20 * rng.random(d)
+    amax = 10 + 2 * rng.random(d)
+    return way, np.stack([-vmax, vmax], 1), np.stack([-amax, amax], 1)
+
+
+@pytest.mark.parametrize("d,N,scheme,sd", [(7, 200, 1, (0, 0)), (6, 500, 1, (0, 0)), (3, 60, 0, (0.1, 0.05)),
+                                           (2, 40, 1, (3.0, 0.0)), (5, 77, 1, (0, 0.2))])
+def test_parameterization_matches_reference(reference, oracle, d, N, scheme, sd):
+    import toppra.algorithm as algo
+    import toppra.constraint as constraint
+    rng = np.random.default_rng(d * 1000 + N)
+    knots = np.linspace(0, 1, 5)
+    grid = np.linspace(0, 1, N + 1)
+    for _ in range(12):
+        way, vl, al = _problem(rng, d)
+        path = reference.SplineInterpolator(knots, way)
+        cons = [constraint.JointVelocityConstraint(vl),
+                constraint.JointAccelerationConstraint(al, discretization_scheme=scheme)]
+        inst = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        sdd, sdv, _, K = inst.compute_parameterization(sd[0], sd[1], return_data=True)
+        flags = oracle.FLAG_VEL | oracle.FLAG_ACC | (oracle.FLAG_INTERP if scheme else 0)
+        w = oracle.Wrapper(path.cspl.c, path.cspl.x, grid, vl, al, flags=flags)
+        st, osdd, osd, oxs, oK = w.compute_parameterization(*sd)
+        assert_same(oK, K, "K")
+        if sdv is None:
+            assert st == 1
+        else:
+            assert_same(osd, sdv, "sd")
+            assert_same(osdd, sdd, "sdd")
+        # wrapper internals: dense rows and the variable box
+        sw = inst.solver_wrapper
+        X = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_feasible_sets()
+        w2 = oracle.Wrapper(path.cspl.c, path.cspl.x, grid, vl, al, flags=flags)
+        assert_same(w2.compute_feasible_sets(), X, "X")
+        assert sw.get_no_stages() == N
+
+
+def test_lp2d_matches_reference(reference, oracle):
+    import toppra.solverwrapper.cy_seidel_solverwrapper as seidel
+    for seed in range(300):
+        rng = np.random.default_rng(seed + 5000)
+        n = int(rng.integers(1, 60))
+        v = rng.standard_normal(3)
+        a, b = rng.standard_normal((2, n))
+        c = -rng.random(n) if seed % 2 == 0 else rng.standard_normal(n)
+        low, high = np.array([-0.5, -0.9]), np.array([0.5, 0.9])
+        ac = rng.integers(-1, n + 1, size=2)
+        want = seidel.solve_lp2d(v, a, b, c, low, high, ac.astype(int))
+        got = oracle.lp2d(v, a, b, c, low, high, ac)
+        assert got[0] == want[0]
+        if want[0]:
+            assert got[1] == want[1] and list(got[2]) == list(want[2]) and list(got[3]) == list(want[3])
+
+
+def test_velocity_bound_is_fp32(reference, oracle):
+    """The fp32 rounding of the velocity bound (SURVEY.md trap 1) is reproduced exactly."""
+    from toppra._CythonUtils import _create_velocity_constraint
+    rng = np.random.default_rng(3)
+    qs = rng.standard_normal((500, 7))
+    qs[::17] = 0.0
+    vmax = 10 + 20 * rng.random(7)
+    vlim = np.stack([-vmax, 0.5 * vmax + rng.random(7)], 1)
+    vlim[3] = [0.5, 2.0]  # positive lower limit exercises the sdmin branch
+    _, _, cc = _create_velocity_constraint(qs, vlim)
+    want = np.stack([cc[:, 1], -cc[:, 0]], 1)
+    got = np.array([oracle.velocity_xbound(q, vlim) for q in qs])
+    assert_same(got, want, "xbound")
+    # and it is NOT what fp64 arithmetic would give
+    assert np.any(got[:, 1] != np.array([np.min(np.where(q > 0, vlim[:, 1] / q, vlim[:, 0] / q)) ** 2
+                                         for q in np.where(qs == 0, 1e-30, qs)]))

@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference (hungpham2511/toppra, seidel solver)
+in the build container.  The reference cannot travel to the GPU box, so its outputs are committed
+as small fixtures; this script is their provenance.
+
+    python tools/make_golden.py        # needs /root/reference; builds oracle/_ref on demand
+
+Every fixture stores the inputs in the C-ABI layout (coef [B,4,nseg,d], breaks, grid, vlim, alim,
+sd_start, sd_end) and the reference's outputs.  Trajectories the reference declares
+FailUncontrollable (it returns None) are stored NaN-filled with status 1.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import ref_loader  # noqa: E402
+
+ta = ref_loader.load()
+if ta is None:
+    raise SystemExit("reference not available")
+import toppra.algorithm as algo  # noqa: E402
+import toppra.constraint as constraint  # noqa: E402
+from toppra.algorithm.algorithm import ParameterizationReturnCode as RC  # noqa: E402
+
+STATUS = {RC.Ok: 0, RC.FailUncontrollable: 1, RC.ErrUnknown: 2}
+
+
+def solve_one(knots, way, grid, vl, al, sd0=0.0, sd1=0.0, scheme=1, want_feasible=False, bc="not-a-knot"):
+    path = ta.SplineInterpolator(knots, way, bc_type=bc)
+    cons = []
+    if vl is not None:
+        cons.append(constraint.JointVelocityConstraint(vl))
+    if al is not None:
+        cons.append(constraint.JointAccelerationConstraint(al, discretization_scheme=scheme))
+    inst = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+    sdd, sd, _, K = inst.compute_parameterization(sd0, sd1, return_data=True)
+    N = len(grid) - 1
+    st = STATUS[inst.problem_data.return_code]
+    if sd is None:
+        sd = np.full(N + 1, np.nan)
+        sdd = np.full(N, np.nan)
+    rec = {"coef": np.asarray(path.cspl.c), "breaks": np.asarray(path.cspl.x), "K": K, "sd": sd,
+           "sd2": sd ** 2 if st else None, "u": sdd, "status": st}
+    if want_feasible:
+        # fresh instance: the reference's warm-start state is per object
+        inst2 = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        rec["X"] = inst2.compute_feasible_sets()
+    return rec, inst, path, cons
+
+
+def xs_from(inst_or_none, sd):
+    return sd
+
+
+def batch_fixture(name, B, d, N, seed, sd_mode="zero", scheme=1, feasible=False, with_vel=True,
+                  vscale=1.0, ascale=1.0, wayscale=None):
+    rng = np.random.default_rng(seed)
+    way = rng.standard_normal((B, 5, d))
+    if wayscale is not None:  # tiny motions: the reference's seidel path degrades here
+        way = way * (10.0 ** rng.uniform(wayscale[0], wayscale[1], size=(B, 1, 1)))
+    vmax = (10 + 20 * rng.random((B, d))) * vscale
+    amax = (10 + 2 * rng.random((B, d))) * ascale
+    knots = np.linspace(0, 1, 5)
+    grid = np.linspace(0, 1, N + 1)
+    sd0 = np.zeros(B)
+    sd1 = np.zeros(B)
+    if sd_mode == "random":
+        sd0 = 0.15 * rng.random(B)
+        sd1 = 0.15 * rng.random(B)
+        sd0[::5] = 6.0  # uncontrollable starts
+    recs = []
+    for b in range(B):
+        vl = np.stack([-vmax[b], vmax[b]], axis=1) if with_vel else None
+        al = np.stack([-amax[b], amax[b]], axis=1)
+        rec, inst, path, cons = solve_one(knots, way[b], grid, vl, al, sd0[b], sd1[b], scheme, feasible)
+        recs.append(rec)
+    out = {
+        "coef": np.stack([r["coef"] for r in recs]), "breaks": recs[0]["breaks"], "grid": grid,
+        "alim": np.stack([-amax, amax], axis=-1), "sd_start": sd0, "sd_end": sd1,
+        "K": np.stack([r["K"] for r in recs]), "sd": np.stack([r["sd"] for r in recs]),
+        "u": np.stack([r["u"] for r in recs]), "status": np.array([r["status"] for r in recs], dtype=np.int32),
+        "interpolation": np.array(scheme),
+    }
+    if with_vel:
+        out["vlim"] = np.stack([-vmax, vmax], axis=-1)
+    if feasible:
+        out["X"] = np.stack([r["X"] for r in recs])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "status counts", np.bincount(out["status"], minlength=3))
+
+
+def example_fixture():
+    """Config 1: examples/plot_kinematics.py (seed 9, 7 dof) on a forced N=100 grid and on the
+    automatically proposed grid; plus constraint parameters and a sample of stagewise solves."""
+    np.random.seed(9)
+    N_samples, dof = 5, 7
+    way_pts = np.random.randn(N_samples, dof)
+    knots = np.linspace(0, 1, 5)
+    vlim_ = 10 + np.random.rand(dof) * 20
+    alim_ = 10 + np.random.rand(dof) * 2
+    vl = np.vstack((-vlim_, vlim_)).T
+    al = np.vstack((-alim_, alim_)).T
+    out = {"way_pts": way_pts, "knots": knots, "vlim": vl[None], "alim": al[None]}
+    for tag, grid in (("n100", np.linspace(0, 1, 101)), ("auto", None)):
+        path = ta.SplineInterpolator(knots, way_pts)
+        if grid is None:
+            inst0 = algo.TOPPRA([constraint.JointVelocityConstraint(vl), constraint.JointAccelerationConstraint(al)],
+                                path, solver_wrapper="seidel")
+            grid = inst0.gridpoints
+        rec, inst, path, cons = solve_one(knots, way_pts, grid, vl, al, want_feasible=True)
+        out["coef"] = rec["coef"][None]
+        out["breaks"] = rec["breaks"]
+        for k in ("K", "sd", "u", "X"):
+            out[tag + "_" + k] = rec[k]
+        out[tag + "_grid"] = np.asarray(grid)
+        out[tag + "_status"] = np.array(rec["status"])
+        # constraint parameters (compute_constraint_params) and the wrapper's dense rows
+        pv = cons[0].compute_constraint_params(path, grid)
+        pa = cons[1].compute_constraint_params(path, grid)
+        out[tag + "_xbound"] = pv[6]
+        out[tag + "_acc_a"], out[tag + "_acc_b"], out[tag + "_acc_c"] = pa[0], pa[1], pa[2]
+        out[tag + "_acc_F"], out[tag + "_acc_g"] = pa[3], pa[4]
+        out[tag + "_qs"] = path(grid, 1)
+        out[tag + "_qss"] = path(grid, 2)
+        if tag == "n100":
+            # stagewise solves on a fresh wrapper, the reference's own call sequence preserved
+            from toppra.solverwrapper.cy_seidel_solverwrapper import seidelWrapper
+            for lp1d in (0, 1):
+                w = seidelWrapper(cons, path, grid, solve_lp1d=lp1d)
+                rng = np.random.default_rng(100 + lp1d)
+                q = []
+                r = []
+                for _ in range(64):
+                    i = int(rng.integers(0, 101))
+                    g = rng.standard_normal(2)
+                    mode = int(rng.integers(0, 4))
+                    x = 5 * rng.random()
+                    xb = [np.nan, np.nan, np.nan, np.nan]
+                    if mode == 1:
+                        xb = [x, x, 0.0, 50 * rng.random()]
+                    elif mode == 2:
+                        xb = [0.0, 30 * rng.random(), np.nan, 40 * rng.random()]
+                    elif mode == 3:
+                        xb = [2.0, 1.0, 0.0, 1.0]  # inverted bounds -> infeasible
+                    res = np.array(w.solve_stagewise_optim(i, None, g, *xb))
+                    q.append([i, g[0], g[1]] + xb)
+                    r.append(res)
+                out["stagewise_q_lp1d%d" % lp1d] = np.array(q)
+                out["stagewise_r_lp1d%d" % lp1d] = np.array(r)
+    np.savez_compressed(os.path.join(OUT, "example_kinematics_seed9.npz"), **out)
+    print("example_kinematics_seed9: N auto =", len(out["auto_grid"]) - 1, "status", out["n100_status"], out["auto_status"])
+
+
+def cpp_fixture():
+    """cpp/tests/test_algorithm.cpp:25-58 scenario (2 dof, Collocation, 51 gridpoints) solved by
+    the Python seidel path; the C++ test's own 8-digit vectors are restated in
+    tests/golden/kat_vectors.json."""
+    knots = [0, 1, 2, 3]
+    way = np.array([[0, 0], [1, 3], [2, 4], [0, 0]], dtype=float)
+    grid = np.linspace(0, 3, 51)
+    vl = np.array([[-1.0, 1.0]] * 2)
+    al = np.array([[-0.2, 0.2]] * 2)
+    rec, inst, path, cons = solve_one(knots, way, grid, vl, al, scheme=0, want_feasible=True)
+    np.savez_compressed(os.path.join(OUT, "cpp_scenario_collocation.npz"), coef=rec["coef"][None],
+                        breaks=rec["breaks"], grid=grid, vlim=vl[None], alim=al[None], K=rec["K"],
+                        sd=rec["sd"], u=rec["u"], X=rec["X"], status=np.array(rec["status"]))
+    print("cpp_scenario_collocation status", rec["status"])
+
+
+def lp_fixture():
+    """Random 2-D / 1-D LPs answered by the reference's own solve_lp2d / solve_lp1d (the shape of
+    tests/tests/lpsolvers/seidel/test_lp2d.py:74-115, which needs cvxpy to run there)."""
+    import toppra.solverwrapper.cy_seidel_solverwrapper as seidel
+    n, d = 200, 50
+    V, A, Bm, Cm, LO, HI, AC = [], [], [], [], [], [], []
+    RES, VAL, VAR, ACO = [], [], [], []
+    for seed in range(n):
+        rng = np.random.default_rng(seed)
+        v = rng.standard_normal(3)
+        a, b = rng.standard_normal((2, d))
+        c = -rng.random(d) if seed % 2 == 0 else rng.standard_normal(d)
+        low = np.array([-0.5, -0.9])
+        high = np.array([0.5, 0.9])
+        if seed % 7 == 3:
+            high = np.array([0.5, -1.0])  # inverted box
+        ac = rng.integers(-2, d + 2, size=2)
+        res, val, var, aco = seidel.solve_lp2d(v, a, b, c, low, high, ac.astype(int))
+        V.append(v); A.append(a); Bm.append(b); Cm.append(c); LO.append(low); HI.append(high); AC.append(ac)
+        RES.append(res)
+        VAL.append(val if res else np.nan)
+        VAR.append(np.array(var) if res else [np.nan, np.nan])
+        ACO.append(np.array(aco) if res else [0, 0])
+    out = dict(v=np.array(V), a=np.array(A), b=np.array(Bm), c=np.array(Cm), low=np.array(LO), high=np.array(HI),
+               active_in=np.array(AC, dtype=np.int32), result=np.array(RES, dtype=np.int32), optval=np.array(VAL),
+               optvar=np.array(VAR), active_out=np.array(ACO, dtype=np.int32))
+    # 1-D
+    V1, A1, B1, LO1, HI1, R1, VAL1, VAR1, AC1 = [], [], [], [], [], [], [], [], []
+    for seed in range(n):
+        rng = np.random.default_rng(1000 + seed)
+        v = rng.standard_normal(2)
+        a = rng.standard_normal(30)
+        a[rng.random(30) < 0.2] = 1e-11  # exercised: |a| <= TINY rows are ignored
+        b = rng.standard_normal(30) - (1.0 if seed % 2 else 0.0)
+        low, high = -3 * rng.random(), 3 * rng.random()
+        res, val, var, ac = seidel.solve_lp1d(v, a, b, low, high)
+        V1.append(v); A1.append(a); B1.append(b); LO1.append(low); HI1.append(high)
+        R1.append(res); VAL1.append(val if res else np.nan); VAR1.append(var if res else np.nan); AC1.append(ac if res else 0)
+    out.update(v1=np.array(V1), a1=np.array(A1), b1=np.array(B1), low1=np.array(LO1), high1=np.array(HI1),
+               result1=np.array(R1, dtype=np.int32), optval1=np.array(VAL1), optvar1=np.array(VAR1),
+               active1=np.array(AC1, dtype=np.int32))
+    np.savez_compressed(os.path.join(OUT, "random_lps.npz"), **out)
+    print("random_lps: feasible 2-D", int(np.sum(out["result"])), "of", n, "; 1-D", int(np.sum(out["result1"])))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    example_fixture()
+    cpp_fixture()
+    lp_fixture()
+    batch_fixture("batch_d7_N200", 32, 7, 200, seed=20240924)
+    batch_fixture("batch_d6_N500", 8, 6, 500, seed=20240925)
+    batch_fixture("batch_d7_N100_boundary", 40, 7, 100, seed=77, sd_mode="random", feasible=True)
+    batch_fixture("batch_d3_N60_collocation", 24, 3, 60, seed=5, scheme=0, feasible=True)
+    batch_fixture("batch_d4_N80_acc_only", 16, 4, 80, seed=6, with_vel=False)
+    batch_fixture("batch_d7_N120_tight", 24, 7, 120, seed=8, vscale=0.02, ascale=0.02, feasible=True)
+    batch_fixture("batch_d5_N100_tiny_motion", 48, 5, 100, seed=9, wayscale=(-5.5, -0.5))

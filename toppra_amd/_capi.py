@@ -54,6 +54,20 @@ _lock = threading.Lock()
 _inited_device = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (soname
+    libamdhip64.so.7, but requested by torch under the unversioned name), so if this library pulled
+    in /opt/rocm's copy first, a later ``import torch`` would load a second runtime that sees no
+    GPU.  Importing torch first makes the dynamic loader bind our NEEDED libamdhip64.so.7 to the
+    copy torch already loaded.  Set TOPPRA_HIP_NO_TORCH=1 to skip (torch-free deployments)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("TOPPRA_HIP_NO_TORCH"):
+        return
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load():
     """dlopen the library and declare signatures (no GPU needed for this step)."""
     global _lib
@@ -64,6 +78,7 @@ def load():
             raise ToppraHipError(
                 "libtoppra_hip.so is not built: run `python -m toppra_amd.build` "
                 "(there is no CPU fallback for the TOPP-RA path)")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         L.tpr_init.restype = C.c_int
         L.tpr_init.argtypes = [C.c_int]
@@ -80,7 +95,7 @@ def load():
         L.tpr_feasible_sets_batch.restype = C.c_int
         L.tpr_feasible_sets_batch.argtypes = [P, V, V]
         L.tpr_constraint_params_batch.restype = C.c_int
-        L.tpr_constraint_params_batch.argtypes = [P, V, V, V, V, V, V, V, V]
+        L.tpr_constraint_params_batch.argtypes = [P, V, V, V, V, V, V, V, V, V]
         L.tpr_solve_stagewise_batch.restype = C.c_int
         L.tpr_solve_stagewise_batch.argtypes = [P, V, V, V, V, C.c_int, V, V]
         L.tpr_lp1d_batch.restype = C.c_int

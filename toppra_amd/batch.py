@@ -101,16 +101,16 @@ def feasible_sets_batch(coef, breaks, grid, vlim, alim, interpolation=True):
 def constraint_params_batch(coef, breaks, grid, vlim, alim, interpolation=True):
     """compute_constraint_params + seidelWrapper row build for B trajectories.
 
-    Returns dict(a,b,c [B,N+1,nC], low, high [B,N+1,2], qs, qss [B,N+1,d])."""
+    Returns dict(a,b,c [B,N+1,nC], low, high, xbound [B,N+1,2], qs, qss [B,N+1,d])."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation)
     nC = 2 + ((4 if interpolation else 2) * p.d if alim is not None else 0)
     B, N, d = p.B, p.N, p.d
     out = {k: _empty(coef, (B, N + 1, nC)) for k in ("a", "b", "c")}
-    out.update({k: _empty(coef, (B, N + 1, 2)) for k in ("low", "high")})
+    out.update({k: _empty(coef, (B, N + 1, 2)) for k in ("low", "high", "xbound")})
     out.update({k: _empty(coef, (B, N + 1, d)) for k in ("qs", "qss")})
     _capi.check(_capi.load().tpr_constraint_params_batch(
-        C.byref(p), *[_capi.ptr(out[k]) for k in ("a", "b", "c", "low", "high", "qs", "qss")],
+        C.byref(p), *[_capi.ptr(out[k]) for k in ("a", "b", "c", "low", "high", "xbound", "qs", "qss")],
         _stream_ptr(coef)))
     return out
 

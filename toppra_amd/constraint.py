@@ -1,0 +1,148 @@
+"""Constraint classes of the hot path: joint velocity and joint acceleration limits.
+
+Same class names, constructor arguments and error behaviour as toppra/constraint/
+(linear_joint_velocity.py:8-53, linear_joint_acceleration.py:8-104, constraint.py:10-103).
+``compute_constraint_params`` returns the reference's 7-tuple ``(a, b, c, F, g, ubound, xbound)``
+but the numbers come from the HIP library (``tpr_constraint_params_batch``), not from numpy.
+"""
+from enum import Enum
+
+import numpy as np
+
+from . import batch as _batch
+from .interpolator import spline_tables
+
+
+class ConstraintType(Enum):
+    Unknown = -1
+    CanonicalLinear = 0
+    CanonicalConic = 1
+
+
+class DiscretizationType(Enum):
+    Collocation = 0
+    Interpolation = 1
+
+
+class Constraint(object):
+    """Base class (constraint.py:34-103)."""
+
+    constraint_type = ConstraintType.Unknown
+    discretization_type = DiscretizationType.Collocation
+    n_extra_vars = 0
+    dof = -1
+    _format_string = ""
+
+    def __repr__(self):
+        return "%s(\n    Type: %s\n    Discretization Scheme: %s\n%s)" % (
+            self.__class__.__name__, self.constraint_type, self.discretization_type, self._format_string)
+
+    def get_dof(self):
+        return self.dof
+
+    def get_no_extra_vars(self):
+        return self.n_extra_vars
+
+    def get_constraint_type(self):
+        return self.constraint_type
+
+    def get_discretization_type(self):
+        return self.discretization_type
+
+    def set_discretization_type(self, discretization_type):
+        if discretization_type in (0, DiscretizationType.Collocation):
+            self.discretization_type = DiscretizationType.Collocation
+        elif discretization_type in (1, DiscretizationType.Interpolation):
+            self.discretization_type = DiscretizationType.Interpolation
+        elif getattr(discretization_type, "value", None) in (0, 1):  # the reference's own enum
+            self.discretization_type = DiscretizationType(discretization_type.value)
+        else:
+            raise NotImplementedError("Discretization type: %s not implemented!" % (discretization_type,))
+
+    def compute_constraint_params(self, path, gridpoints, *args, **kwargs):
+        raise NotImplementedError
+
+
+class LinearConstraint(Constraint):
+    """Canonical linear constraint a u + b x + c in {F v <= g} (linear_constraint.py:9-81)."""
+
+    def __init__(self):
+        self.constraint_type = ConstraintType.CanonicalLinear
+        self.discretization_type = DiscretizationType.Collocation
+        self.n_extra_vars = 0
+        self.dof = -1
+        self.identical = False
+
+
+def _limits(lim, what):
+    lim = np.array(lim, dtype=float)
+    if np.isnan(lim).any():
+        raise ValueError("Bad %s given: %s" % (what, lim))
+    if lim.ndim == 1:
+        lim = np.vstack((-lim, lim)).T
+    assert lim.shape[1] == 2, "Wrong input shape."
+    return lim
+
+
+def _check_dof(constraint, path):
+    if path.dof != constraint.get_dof():
+        raise ValueError("Wrong dimension: constraint dof ({:d}) not equal to path dof ({:d})".format(
+            constraint.get_dof(), path.dof))
+
+
+def _params_on_device(path, gridpoints, vlim=None, alim=None, interpolation=True):
+    coef, breaks = spline_tables(path)
+    return _batch.constraint_params_batch(
+        coef[None], breaks, np.asarray(gridpoints, dtype=np.float64),
+        None if vlim is None else vlim[None], None if alim is None else alim[None], interpolation)
+
+
+class JointVelocityConstraint(LinearConstraint):
+    """vlim[j, 0] <= qdot_j <= vlim[j, 1]; becomes a bound on x = sd^2 at every gridpoint."""
+
+    def __init__(self, vlim):
+        super(JointVelocityConstraint, self).__init__()
+        self.vlim = _limits(vlim, "velocity")
+        self.dof = self.vlim.shape[0]
+        for i in range(self.dof):
+            if self.vlim[i, 0] >= self.vlim[i, 1]:
+                raise ValueError("Bad velocity limits: {:} (lower limit) > {:} (higher limit)".format(
+                    self.vlim[i, 0], self.vlim[i, 1]))
+        self._format_string = "    Velocity limit: \n" + "".join(
+            "      J{:d}: {:}\n".format(i + 1, self.vlim[i]) for i in range(self.dof))
+
+    def compute_constraint_params(self, path, gridpoints, *args, **kwargs):
+        _check_dof(self, path)
+        out = _params_on_device(path, gridpoints, vlim=self.vlim)
+        return None, None, None, None, None, None, np.array(out["xbound"][0])
+
+
+class JointAccelerationConstraint(LinearConstraint):
+    """alim[j, 0] <= q'_j u + q''_j x <= alim[j, 1] (Interpolation scheme by default)."""
+
+    def __init__(self, alim, discretization_scheme=DiscretizationType.Interpolation):
+        super(JointAccelerationConstraint, self).__init__()
+        self.alim = _limits(alim, "velocity")  # sic: the reference's message says "velocity" too
+        self.dof = self.alim.shape[0]
+        self.set_discretization_type(discretization_scheme)
+        self._format_string = "    Acceleration limit: \n" + "".join(
+            "      J{:d}: {:}\n".format(i + 1, self.alim[i]) for i in range(self.dof))
+        self.identical = True
+
+    def compute_constraint_params(self, path, gridpoints, *args, **kwargs):
+        _check_dof(self, path)
+        interp = self.discretization_type == DiscretizationType.Interpolation
+        out = _params_on_device(path, gridpoints, alim=self.alim, interpolation=interp)
+        d = self.dof
+        eye = np.vstack([np.eye(d), -np.eye(d)])
+        g1 = np.concatenate([self.alim[:, 1], -self.alim[:, 0]])
+        if not interp:
+            a, b = out["a"][0, :, 2:2 + d], out["b"][0, :, 2:2 + d]
+            return a, b, np.zeros_like(a), eye, g1, None, None
+        # wrapper rows are [ +a_i | -a_i | +a~ | -a~ ]; the constraint-level a is [ a_i | a~ ]
+        pick = np.r_[2:2 + d, 2 + 2 * d:2 + 3 * d]
+        a, b = out["a"][0][:, pick], out["b"][0][:, pick]
+        F = np.zeros((4 * d, 2 * d))
+        F[:2 * d, :d] = eye
+        F[2 * d:, d:] = eye
+        return a, b, np.zeros_like(a), F, np.concatenate([g1, g1]), None, None

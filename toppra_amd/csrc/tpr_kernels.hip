@@ -259,19 +259,19 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
 }
 
 int tpr_constraint_params_batch(const tpr_problem *p, double *a, double *b, double *c, double *low,
-                                double *high, double *qs, double *qss, void *stream_) {
+                                double *high, double *xbound, double *qs, double *qss, void *stream_) {
     if (int rc = check_problem(p)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     const size_t pts = (size_t)p->B * (p->N + 1), nC = (size_t)rows_per_lp(p);
     double *da = S.out(a, pts * nC), *db = S.out(b, pts * nC), *dc = S.out(c, pts * nC);
-    double *dlow = S.out(low, pts * 2), *dhigh = S.out(high, pts * 2);
+    double *dlow = S.out(low, pts * 2), *dhigh = S.out(high, pts * 2), *dxb = S.out(xbound, pts * 2);
     double *dqs = S.out(qs, pts * p->d), *dqss = S.out(qss, pts * p->d);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (pts > 0)
         hipLaunchKernelGGL(tpr::params_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, stream, A,
-                           da, db, dc, dlow, dhigh, dqs, dqss);
+                           da, db, dc, dlow, dhigh, dxb, dqs, dqss);
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }

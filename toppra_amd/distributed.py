@@ -1,0 +1,70 @@
+"""Multi-GPU sharding of a trajectory batch: one process per GPU, no data-path collective.
+
+Trajectories are independent, so a batch of B problems is cut into contiguous shards, every rank
+solves its shard with the single-GPU kernels, and the only communication is the final gather of
+``sd^2 [B_local, N+1]`` to rank 0 (RCCL over xGMI with the ``nccl`` backend; ``gloo`` on CPU for the
+tests).  On the fully connected xGMI mesh a gather to one root uses the root's seven inbound
+links concurrently, which is why this is a gather and not a ring all-gather.
+"""
+import numpy as np
+
+
+def shard_bounds(total, world_size, rank):
+    """Contiguous [lo, hi) of `total` items owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(int(total), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_problem(arrays, world_size, rank):
+    """Slice every per-trajectory array (leading dim == B of arrays['coef']) to this rank's shard;
+    shared arrays (1-D grid / breaks) pass through."""
+    B = arrays["coef"].shape[0]
+    lo, hi = shard_bounds(B, world_size, rank)
+    out = {}
+    for k, v in arrays.items():
+        per_traj = v is not None and hasattr(v, "shape") and len(v.shape) >= 1 and v.shape[0] == B and not (
+            k in ("grid", "breaks") and len(v.shape) == 1)
+        out[k] = v[lo:hi] if per_traj else v
+    return out, (lo, hi)
+
+
+def gather_rows(local, total_rows, dst=0, group=None):
+    """Gather row-sharded tensors ``local [B_local, ...]`` (torch, contiguous shards in rank order)
+    to rank `dst`.  Returns the full ``[total_rows, ...]`` tensor on `dst`, None elsewhere.
+    Ragged shards (B % world != 0) are padded to the largest shard for the collective."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local
+    sizes = [shard_bounds(total_rows, world, r) for r in range(world)]
+    rows = max(hi - lo for lo, hi in sizes)
+    send = local
+    if local.shape[0] != rows:
+        send = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local
+    send = send.contiguous()
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def solve_sharded(arrays, solve_fn, to_tensor, dst=0, group=None):
+    """Shard -> solve locally -> gather sd^2 on `dst`.
+
+    `solve_fn(shard_arrays) -> dict with 'sd2'` is the single-GPU solver
+    (``toppra_amd.batch.solve_batch`` on device tensors); `to_tensor` converts its 'sd2' to a torch
+    tensor on the collective's device.  Returns (local_result, full_sd2_or_None)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    shard, _ = shard_problem(arrays, world, rank)
+    local = solve_fn(shard)
+    full = gather_rows(to_tensor(local["sd2"]), arrays["coef"].shape[0], dst=dst, group=group)
+    return local, full

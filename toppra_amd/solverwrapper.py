@@ -1,0 +1,142 @@
+"""Solver wrapper of the HIP path: the reference's ``SolverWrapper`` contract
+(solverwrapper/solverwrapper.py:49-166) with ``seidelWrapper``'s concrete signatures
+(cy_seidel_solverwrapper.pyx:425-544, :549-703).
+
+``hipSeidelWrapper`` owns one (constraints, path, grid) problem.  The pass-level methods
+(``controllable_sets`` / ``parameterization`` / ``feasible_sets``) are what the algorithm layer
+calls -- one kernel launch per pass instead of 3N Python->solver round trips.
+``solve_stagewise_optim`` is kept as the single-LP compatibility entry with the reference's
+stateful warm start (``active_c_up`` / ``active_c_down`` persist between calls).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi, batch
+from .interpolator import spline_tables
+
+
+def available_solvers(output_msg=True):
+    """Mirror of solverwrapper.available_solvers(): name/availability pairs, best first."""
+    try:
+        ok = _capi.device_count() > 0
+    except Exception:
+        ok = False
+    avail = (("hip", ok),)
+    if output_msg:
+        print(avail)
+    return avail
+
+
+def extract_limits(constraint_list, dof):
+    """(vlim, alim, interpolation) from a constraint list -- ours or the reference's classes
+    (duck-typed on .vlim / .alim / .discretization_type).  Anything else is refused the way
+    seidelWrapper refuses non-canonical-linear constraints (cy_seidel_solverwrapper.pyx:459-460)."""
+    vlim = alim = None
+    interpolation = True
+    for c in constraint_list:
+        ctype = getattr(c.get_constraint_type(), "value", None)
+        if ctype != 0:
+            raise NotImplementedError("the seidel path handles CanonicalLinear constraints only")
+        if hasattr(c, "vlim") and not hasattr(c, "vlim_func"):
+            if vlim is not None:
+                raise NotImplementedError("more than one JointVelocityConstraint")
+            vlim = np.ascontiguousarray(c.vlim, dtype=np.float64)
+        elif hasattr(c, "alim"):
+            if alim is not None:
+                raise NotImplementedError("more than one JointAccelerationConstraint")
+            alim = np.ascontiguousarray(c.alim, dtype=np.float64)
+            interpolation = getattr(c.get_discretization_type(), "value", 1) == 1
+        else:
+            raise NotImplementedError(
+                "%s is outside the HIP path (JointVelocityConstraint and JointAccelerationConstraint "
+                "are supported)" % type(c).__name__)
+        if c.get_dof() != dof:
+            raise ValueError("Wrong dimension: constraint dof ({:d}) not equal to path dof ({:d})".format(
+                c.get_dof(), dof))
+    return vlim, alim, interpolation
+
+
+class SolverWrapper(object):
+    """Interface (solverwrapper.py:49-166)."""
+
+    def get_no_stages(self):
+        return self.N
+
+    def get_no_vars(self):
+        return self.nV
+
+    def get_deltas(self):
+        return self.deltas
+
+    def solve_stagewise_optim(self, i, H, g, x_min, x_max, x_next_min, x_next_max):
+        raise NotImplementedError
+
+    def setup_solver(self):
+        pass
+
+    def close_solver(self):
+        pass
+
+
+class hipSeidelWrapper(SolverWrapper):
+    """Seidel LP wrapper running on the MI355X.
+
+    Parameters as seidelWrapper: ``constraint_list``, ``path``, ``path_discretization``,
+    ``solve_lp1d`` (solve the 1-variable LP when x_min == x_max)."""
+
+    def __init__(self, constraint_list, path, path_discretization, solve_lp1d=0):
+        self.constraints = constraint_list
+        self.path = path
+        self.path_discretization = np.array(path_discretization, dtype=np.float64)
+        self.N = len(self.path_discretization) - 1
+        self.deltas = self.path_discretization[1:] - self.path_discretization[:-1]
+        self.nV = 2
+        self._solve_lp1d = int(solve_lp1d)
+        coef, breaks = spline_tables(path)
+        self._coef, self._breaks = coef[None], breaks
+        self.dof = coef.shape[2]
+        vlim, alim, self._interp = extract_limits(constraint_list, self.dof)
+        self._vlim = None if vlim is None else vlim[None]
+        self._alim = None if alim is None else alim[None]
+        self.nC = 2 + (0 if alim is None else (4 if self._interp else 2) * self.dof)
+        # warm-start state of the two LP "solvers", as in the reference object
+        self._active = np.zeros((1, 4), dtype=np.int32)
+        self._params = None  # device init is lazy: every compute entry calls _capi.init()
+
+    @property
+    def params(self):
+        if self._params is None:
+            self._params = [c.compute_constraint_params(self.path, self.path_discretization)
+                            for c in self.constraints]
+        return self._params
+
+    # -- pass-level entries ------------------------------------------------------------------
+    def _args(self):
+        return self._coef, self._breaks, self.path_discretization, self._vlim, self._alim
+
+    def controllable_sets(self, sdmin, sdmax):
+        return batch.controllable_sets_batch(*self._args(), np.array([sdmin], dtype=np.float64),
+                                             np.array([sdmax], dtype=np.float64), self._interp)[0]
+
+    def feasible_sets(self):
+        return batch.feasible_sets_batch(*self._args(), self._interp)[0]
+
+    def parameterization(self, sd_start, sd_end):
+        out = batch.solve_batch(*self._args(), np.array([sd_start], dtype=np.float64),
+                                np.array([sd_end], dtype=np.float64), self._interp, want_sd=True)
+        return {k: v[0] for k, v in out.items()}
+
+    # -- single-LP compatibility entry ---------------------------------------------------------
+    def solve_stagewise_optim(self, i, H, g, x_min, x_max, x_next_min, x_next_max):
+        assert 0 <= i <= self.N
+        _capi.init()
+        p, keep = _capi.make_problem(*self._args(), None, None, self._interp)
+        stage = np.array([i], dtype=np.int32)
+        g = np.ascontiguousarray(np.asarray(g, dtype=np.float64)[:2].reshape(1, 2))
+        xb = np.array([[x_min, x_max, x_next_min, x_next_max]], dtype=np.float64)
+        out = np.empty((1, 2))
+        _capi.check(_capi.load().tpr_solve_stagewise_batch(
+            C.byref(p), _capi.ptr(stage), _capi.ptr(g), _capi.ptr(xb), _capi.ptr(self._active),
+            self._solve_lp1d, _capi.ptr(out), None))
+        return out[0]
