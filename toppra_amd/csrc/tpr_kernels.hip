@@ -107,21 +107,40 @@ tpr::BatchArgs stage_problem(const tpr_problem *p, Staging &S) {
     return A;
 }
 
+constexpr size_t kMaxDynamicLds = 64 * 1024;
+
 template <int D, int L>
-void launch_group(const tpr::BatchArgs &A, hipStream_t stream) {
+size_t group_lds_bytes(int nseg, int threads) {
+    return (size_t)(threads / L) * tpr::GroupCfg<D, L>::lds_doubles(nseg) * sizeof(double);
+}
+
+// Largest block (256, 128 or 64 threads) whose LDS staging area fits; 0 when none does.
+template <int D, int L>
+int group_block_threads(int nseg) {
+    for (int threads = 256; threads >= 64; threads /= 2)
+        if (group_lds_bytes<D, L>(nseg, threads) <= kMaxDynamicLds) return threads;
+    return 0;
+}
+
+template <int D, int L>
+int launch_group(const tpr::BatchArgs &A, hipStream_t stream) {
+    const int threads = group_block_threads<D, L>(A.nseg);
+    if (threads == 0) return fail(TPR_E_UNSUPPORTED, "spline table too large for the LDS staging area");
     tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
                      A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
-    constexpr int groups = 256 / L;
-    const size_t lds = (size_t)groups * 3 * A.nseg * D * sizeof(double);
-    hipLaunchKernelGGL((tpr::group_solve_kernel<D, L>), dim3((A.B + groups - 1) / groups), dim3(256), lds,
+    const int groups = threads / L;
+    const size_t lds = group_lds_bytes<D, L>(A.nseg, threads);
+    hipLaunchKernelGGL((tpr::group_solve_kernel<D, L>), dim3((A.B + groups - 1) / groups), dim3(threads), lds,
                        stream, G);
+    return TPR_E_OK;
 }
 
 // The rows-across-lanes kernels cover the reference's default constraint set (acceleration with
 // Interpolation, velocity optional) for d <= 8 and spline tables that fit the LDS staging area.
 bool group_supported(const tpr::BatchArgs &A) {
     const int need = TPR_HAS_ACCELERATION | TPR_ACC_INTERPOLATION;
-    return (A.flags & need) == need && A.d >= 1 && A.d <= 8 && (size_t)A.nseg * A.d * 3 * 8 * 32 <= 64 * 1024;
+    if ((A.flags & need) != need || A.d < 1 || A.d > 8) return false;
+    return (size_t)(64 / 8) * (3 * A.nseg * A.d + A.nseg + 1 + 3 * (6 + 4 * A.d)) * 8 <= kMaxDynamicLds;
 }
 
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
@@ -129,17 +148,23 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
     int variant = p->variant;
     if (variant == 0) variant = group_supported(A) ? 2 : 1;
     switch (variant) {
+        case 3:  // experiments: other group widths for the 7-dof headline shape
+            if (!group_supported(A) || A.d != 7) return fail(TPR_E_UNSUPPORTED, "variant 3 is d == 7 only");
+            return launch_group<7, 4>(A, stream);
+        case 4:
+            if (!group_supported(A) || A.d != 7) return fail(TPR_E_UNSUPPORTED, "variant 4 is d == 7 only");
+            return launch_group<7, 16>(A, stream);
         case 2: {
             if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 2 needs acceleration+interpolation, d <= 8");
             switch (A.d) {
-                case 1: launch_group<1, 8>(A, stream); break;
-                case 2: launch_group<2, 8>(A, stream); break;
-                case 3: launch_group<3, 8>(A, stream); break;
-                case 4: launch_group<4, 8>(A, stream); break;
-                case 5: launch_group<5, 8>(A, stream); break;
-                case 6: launch_group<6, 8>(A, stream); break;
-                case 7: launch_group<7, 8>(A, stream); break;
-                case 8: launch_group<8, 8>(A, stream); break;
+                case 1: return launch_group<1, 8>(A, stream);
+                case 2: return launch_group<2, 8>(A, stream);
+                case 3: return launch_group<3, 8>(A, stream);
+                case 4: return launch_group<4, 8>(A, stream);
+                case 5: return launch_group<5, 8>(A, stream);
+                case 6: return launch_group<6, 8>(A, stream);
+                case 7: return launch_group<7, 8>(A, stream);
+                case 8: return launch_group<8, 8>(A, stream);
             }
             return TPR_E_OK;
         }
