@@ -36,6 +36,25 @@ def algorithmic_bytes(d, N, nseg):
     return inp + out
 
 
+def pmc_traffic(B, d, N, kernel_ms):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc.json, produced by tools/gpu_profile.sh + tools/pmc_summary.py --json).
+    Only valid for the shape it was collected on; returns None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    try:
+        with open(path) as fh:
+            pmc = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if int(pmc["counters"].get("_Grid_Size", 0)) != B * 8 or (d, N) != (7, 200) or "hbm_bytes_per_launch" not in pmc:
+        return None
+    return {"bytes_per_launch": pmc["hbm_bytes_per_launch"],
+            "bytes_per_launch_fetch_x2": pmc["hbm_bytes_per_launch_fetch_x2"],
+            "gbps": pmc["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9,
+            "valu_busy": pmc.get("valu_busy"), "avg_active_lanes": pmc.get("avg_active_lanes"),
+            "source": "profiles/r01_pmc.json (rocprofv3 --pmc, separate passes)"}
+
+
 def cpu_baseline(data, target_seconds=12.0):
     """The oracle (C port of the reference's seidel path, bit-exact with it) on the host cores,
     on a bounded sample of the same workload."""
@@ -140,6 +159,7 @@ def main():
         bytes_per_traj = algorithmic_bytes(d, N, nseg)
         achieved = bytes_per_traj * B / (kernel_ms * 1e-3) / 1e9
         traj_per_s = world * B * args.steps / elapsed
+        pmc = pmc_traffic(B, d, N, kernel_ms)
         line = {
             "metric": "trajectories/sec (7-DoF N=200 batch; waypoint-LPs/sec = 3N x this)",
             "value": traj_per_s,
@@ -168,10 +188,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc["gbps"] if pmc else None,
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_trajectory": bytes_per_traj,
-                "note": "fused path is fp64-VALU/divergence bound, not HBM bound (DESIGN.md)",
+                "pmc": pmc,
+                "note": "fused path is fp64-VALU bound (VALU busy ~91%), not HBM bound: DESIGN.md section 3.3",
             },
         }
         if not args.no_cpu_baseline:

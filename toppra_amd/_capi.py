@@ -10,7 +10,7 @@ import threading
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtoppra_hip.so")
+LIB_PATH = os.environ.get("TOPPRA_HIP_LIB") or os.path.join(HERE, "libtoppra_hip.so")
 
 MAX_DOF = 16
 HAS_VELOCITY = 1

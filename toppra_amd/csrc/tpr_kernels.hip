@@ -148,12 +148,6 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
     int variant = p->variant;
     if (variant == 0) variant = group_supported(A) ? 2 : 1;
     switch (variant) {
-        case 3:  // experiments: other group widths for the 7-dof headline shape
-            if (!group_supported(A) || A.d != 7) return fail(TPR_E_UNSUPPORTED, "variant 3 is d == 7 only");
-            return launch_group<7, 4>(A, stream);
-        case 4:
-            if (!group_supported(A) || A.d != 7) return fail(TPR_E_UNSUPPORTED, "variant 4 is d == 7 only");
-            return launch_group<7, 16>(A, stream);
         case 2: {
             if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 2 needs acceleration+interpolation, d <= 8");
             switch (A.d) {
