@@ -136,6 +136,19 @@ int tpr_lp2d_batch(int n, int nrows, const double *v, const double *a, const dou
                    int32_t *result, double *optval, double *optvar, int32_t *active_out,
                    void *stream);
 
+/* Replaces SplineInterpolator.__init__ -> scipy.interpolate.CubicSpline (interpolator.py:360-421)
+ * for B paths: waypoints [B][m][d] at knots [m] (knots_per_path == 0) or [B][m] -> coef
+ * [B][4][m-1][d], the layout tpr_problem.coef takes.  Boundary conditions per end:
+ * TPR_BC_NOT_A_KNOT, TPR_BC_FIRST_DERIV (value [B][d], NULL = 0: scipy's "clamped"),
+ * TPR_BC_SECOND_DERIV (NULL = 0: "natural").  2 <= m <= 64.  device_ptrs != 0: all pointers are
+ * device pointers.                                                                                */
+#define TPR_BC_NOT_A_KNOT 0
+#define TPR_BC_FIRST_DERIV 1
+#define TPR_BC_SECOND_DERIV 2
+int tpr_spline_fit_batch(int B, int m, int d, const double *knots, int knots_per_path,
+                         const double *waypoints, int bc_start, int bc_end, const double *bc_start_val,
+                         const double *bc_end_val, double *coef, int device_ptrs, void *stream);
+
 /* Measurement helper used by bench.py: launches the tpr_solve_batch kernel(s) `reps` times on
  * `stream` between two hipEvents recorded on that same stream and returns the average
  * milliseconds per launch (device pointers required).                                            */

@@ -48,6 +48,7 @@ EXPORTS = (
     "tpr_init", "tpr_device_count", "tpr_last_error", "tpr_version", "tpr_solve_batch",
     "tpr_controllable_sets_batch", "tpr_feasible_sets_batch", "tpr_constraint_params_batch",
     "tpr_solve_stagewise_batch", "tpr_lp1d_batch", "tpr_lp2d_batch", "tpr_solve_batch_timed",
+    "tpr_spline_fit_batch",
 )
 
 _lib = None
@@ -99,6 +100,9 @@ def load():
         L.tpr_constraint_params_batch.argtypes = [P, V, V, V, V, V, V, V, V, V]
         L.tpr_solve_stagewise_batch.restype = C.c_int
         L.tpr_solve_stagewise_batch.argtypes = [P, V, V, V, V, C.c_int, V, V]
+        L.tpr_spline_fit_batch.restype = C.c_int
+        L.tpr_spline_fit_batch.argtypes = [C.c_int, C.c_int, C.c_int, V, C.c_int, V, C.c_int, C.c_int, V, V, V,
+                                           C.c_int, V]
         L.tpr_lp1d_batch.restype = C.c_int
         L.tpr_lp1d_batch.argtypes = [C.c_int, C.c_int] + [V] * 10
         L.tpr_lp2d_batch.restype = C.c_int

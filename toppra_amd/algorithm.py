@@ -195,9 +195,17 @@ class BatchTOPPRA(object):
         self.vlim, self.alim, self.interpolation = vlim, alim, interpolation
 
     @classmethod
-    def from_waypoints(cls, knots, waypoints, gridpoints, vlim, alim, bc_type="not-a-knot", **kw):
-        coef, breaks = _batch.spline_coefficients(knots, waypoints, bc_type)
-        return cls(coef, breaks, np.asarray(gridpoints, dtype=np.float64), vlim, alim, **kw)
+    def from_waypoints(cls, knots, waypoints, gridpoints, vlim, alim, bc_type="not-a-knot", gpu_fit=True, **kw):
+        """Build the batch from waypoints [B, m, d].  ``gpu_fit`` selects the batched GPU spline fit
+        (``batch.spline_fit_batch``, bit-identical to scipy for the supported boundary conditions);
+        otherwise one batched scipy ``CubicSpline`` call on the host."""
+        if gpu_fit:
+            coef, breaks = _batch.spline_fit_batch(knots, waypoints, bc_type)
+        else:
+            coef, breaks = _batch.spline_coefficients(knots, waypoints, bc_type)
+        if not hasattr(gridpoints, "data_ptr"):
+            gridpoints = np.asarray(gridpoints, dtype=np.float64)
+        return cls(coef, breaks, gridpoints, vlim, alim, **kw)
 
     def compute_parameterization(self, sd_start=None, sd_end=None, want_sd=True, variant=0, relaxed=False):
         """dict(sd2, sd, u, K, status): per-trajectory results; status 0/1/2 = Ok /

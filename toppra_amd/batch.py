@@ -15,7 +15,7 @@ from . import _capi
 
 __all__ = ["solve_batch", "controllable_sets_batch", "feasible_sets_batch",
            "constraint_params_batch", "make_synthetic_batch", "spline_coefficients",
-           "solve_batch_timed"]
+           "spline_fit_batch", "solve_batch_timed"]
 
 
 def _stream_ptr(like):
@@ -133,6 +133,55 @@ def spline_coefficients(knots, waypoints, bc_type="not-a-knot"):
     cs = CubicSpline(np.asarray(knots, dtype=np.float64), way.transpose(1, 0, 2), bc_type=bc_type)
     # cs.c: [4, m-1, B, d] -> [B, 4, m-1, d]
     return np.ascontiguousarray(cs.c.transpose(2, 0, 1, 3)), np.asarray(cs.x, dtype=np.float64)
+
+
+_BC_KINDS = {"not-a-knot": 0, "clamped": 1, "natural": 2}
+
+
+def _bc(bc, like, B, d):
+    """scipy-style boundary condition -> (kind, value array or None)."""
+    if isinstance(bc, str):
+        if bc not in _BC_KINDS:
+            raise NotImplementedError("bc_type %r is not supported on the GPU (use the scipy host path)" % (bc,))
+        return _BC_KINDS[bc], None
+    order, value = bc
+    if order not in (1, 2):
+        raise ValueError("boundary derivative order must be 1 or 2")
+    if _capi.is_torch_cuda(like):
+        import torch
+        value = torch.as_tensor(value, dtype=torch.float64, device=like.device).expand(B, d).contiguous()
+    else:
+        value = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float64), (B, d)))
+    return int(order), value
+
+
+def spline_fit_batch(knots, waypoints, bc_type="not-a-knot"):
+    """Batched cubic-spline fit on the GPU: waypoints [B, m, d] -> (coef [B, 4, m-1, d], breaks).
+
+    Same construction as scipy's ``CubicSpline`` (which ``SplineInterpolator`` wraps,
+    interpolator.py:419), arithmetic order included; ``bc_type`` is 'not-a-knot', 'clamped',
+    'natural' or a pair ``((order, value), (order, value))`` with order 1 or 2.  numpy in -> numpy out,
+    torch-ROCm tensors in -> tensors out."""
+    _prepare(waypoints)
+    dev = _capi.is_torch_cuda(waypoints)
+    conv = (lambda x: x.contiguous()) if dev else _capi.f64
+    if dev:
+        import torch
+        knots = torch.as_tensor(knots, dtype=torch.float64, device=waypoints.device)
+    way, knots = conv(waypoints), conv(knots)
+    if way.ndim != 3:
+        raise ValueError("waypoints must have shape [B, m, d]")
+    B, m, d = (int(v) for v in way.shape)
+    if int(knots.shape[-1]) != m:
+        raise ValueError("knots must have one entry per waypoint")
+    bc = (bc_type, bc_type) if isinstance(bc_type, str) else bc_type
+    k0, v0 = _bc(bc[0], way, B, d)
+    k1, v1 = _bc(bc[1], way, B, d)
+    coef = _empty(way, (B, 4, m - 1, d))
+    _capi.check(_capi.load().tpr_spline_fit_batch(
+        B, m, d, _capi.ptr(knots), int(knots.ndim == 2), _capi.ptr(way), k0, k1, _capi.ptr(v0), _capi.ptr(v1),
+        _capi.ptr(coef), int(dev), _stream_ptr(way)))
+    return coef, knots
 
 
 def make_synthetic_batch(B, d, N, seed=20240924, n_waypoints=5):

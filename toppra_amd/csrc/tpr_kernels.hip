@@ -13,6 +13,7 @@
 #include "tpr_device.hpp"
 #include "tpr_lane.hip.inc"
 #include "tpr_group.hip.inc"
+#include "tpr_spline.hip.inc"
 
 namespace {
 
@@ -312,6 +313,30 @@ int tpr_solve_stagewise_batch(const tpr_problem *p, const int32_t *stage, const 
     if (A.B > 0)
         hipLaunchKernelGGL(tpr::lane_stagewise_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dstage,
                            dg, dxb, dact, solve_lp1d, dout);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_spline_fit_batch(int B, int m, int d, const double *knots, int knots_per_path,
+                         const double *waypoints, int bc_start, int bc_end, const double *bc_start_val,
+                         const double *bc_end_val, double *coef, int device_ptrs, void *stream_) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (B < 0 || d < 1 || m < 2 || m > tpr::kSplineMaxPts || !knots || !waypoints || !coef)
+        return fail(TPR_E_BADARG, "spline fit needs 2 <= m <= 64 waypoints, knots, waypoints, coef");
+    if (bc_start < 0 || bc_start > 2 || bc_end < 0 || bc_end > 2) return fail(TPR_E_BADARG, "unknown boundary condition");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(device_ptrs != 0, stream);
+    tpr::SplineArgs A{};
+    A.B = B; A.m = m; A.d = d; A.knots_per_path = knots_per_path; A.bc0 = bc_start; A.bc1 = bc_end;
+    A.knots = S.in(knots, (size_t)(knots_per_path ? B : 1) * m);
+    A.way = S.in(waypoints, (size_t)B * m * d);
+    A.bcv0 = S.in(bc_start_val, (size_t)B * d);
+    A.bcv1 = S.in(bc_end_val, (size_t)B * d);
+    A.coef = S.out(coef, (size_t)B * 4 * (m - 1) * d);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    const long long total = (long long)B * d;
+    if (total > 0)
+        hipLaunchKernelGGL(tpr::spline_fit_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, A);
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
