@@ -149,6 +149,16 @@ int tpr_spline_fit_batch(int B, int m, int d, const double *knots, int knots_per
                          const double *waypoints, int bc_start, int bc_end, const double *bc_start_val,
                          const double *bc_end_val, double *coef, int device_ptrs, void *stream);
 
+/* Replaces ParametrizeConstAccel (toppra/parametrizer.py:23-158) for B trajectories of one shape.
+ * times:  _process_parametrization -- sd [B][N+1] -> ts [B][N+1] (running sum in the reference's
+ *         order), us [B][N] (may be NULL).  Only N, B, flags (TPR_GRID_PER_TRAJ, TPR_DEVICE_PTRS) and
+ *         grid of `p` are used.
+ * eval:   __call__(t, order) -- times [B][T] -> out [B][T][d] = q(t) (order 0), dq/dt (1), d2q/dt2 (2),
+ *         using p->coef/breaks/grid and the sd, ts, us arrays of the same trajectories.            */
+int tpr_const_accel_times_batch(const tpr_problem *p, const double *sd, double *ts, double *us, void *stream);
+int tpr_const_accel_eval_batch(const tpr_problem *p, const double *sd, const double *ts, const double *us,
+                               int T, const double *times, int order, double *out, void *stream);
+
 /* Measurement helper used by bench.py: launches the tpr_solve_batch kernel(s) `reps` times on
  * `stream` between two hipEvents recorded on that same stream and returns the average
  * milliseconds per launch (device pointers required).                                            */

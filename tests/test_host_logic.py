@@ -104,3 +104,17 @@ def test_parametrizers_on_golden_profile(example):
     spl = ta.ParametrizeSpline(path, fx["n100_grid"], fx["n100_sd"])
     assert abs(spl.duration - traj.duration) < 1e-9
     np.testing.assert_allclose(spl(spl.duration), path(1.0), atol=1e-9)
+
+
+def test_parametrizers_match_reference_outputs(example):
+    """Host parametrizers vs the reference's own ParametrizeConstAccel / ParametrizeSpline outputs
+    (tests/golden, generated by tools/make_golden.py)."""
+    fx, path, _, _ = example
+    ca = ta.ParametrizeConstAccel(path, fx["n100_grid"], fx["n100_sd"])
+    assert np.array_equal(ca._ts, fx["ca_ts"]) and np.array_equal(ca._us, fx["ca_us"])
+    for order in (0, 1, 2):
+        np.testing.assert_allclose(ca(fx["ca_times"], order), fx["ca_q%d" % order], rtol=1e-12, atol=1e-12)
+    sp = ta.ParametrizeSpline(path, fx["n100_grid"], fx["n100_sd"])
+    assert sp.duration == float(fx["spl_duration"])
+    for order in (0, 1, 2):
+        np.testing.assert_allclose(sp(fx["spl_times"], order), fx["spl_q%d" % order], rtol=1e-12, atol=1e-11)

@@ -128,6 +128,19 @@ def example_fixture():
         out[tag + "_qs"] = path(grid, 1)
         out[tag + "_qss"] = path(grid, 2)
         if tag == "n100":
+            # output parametrizers of the reference on this profile (parametrizer.py)
+            ca = ta.ParametrizeConstAccel(path, grid, rec["sd"])
+            out["ca_ts"], out["ca_us"] = ca._ts, ca._us
+            tt = np.linspace(0, ca.duration, 257)
+            out["ca_times"] = tt
+            for order in (0, 1, 2):
+                out["ca_q%d" % order] = ca(tt, order)
+            sp = ta.ParametrizeSpline(path, grid, rec["sd"])
+            out["spl_duration"] = np.array(sp.duration)
+            ts2 = np.linspace(0, sp.duration, 129)
+            out["spl_times"] = ts2
+            for order in (0, 1, 2):
+                out["spl_q%d" % order] = sp(ts2, order)
             # stagewise solves on a fresh wrapper, the reference's own call sequence preserved
             from toppra.solverwrapper.cy_seidel_solverwrapper import seidelWrapper
             for lp1d in (0, 1):

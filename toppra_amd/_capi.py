@@ -48,7 +48,7 @@ EXPORTS = (
     "tpr_init", "tpr_device_count", "tpr_last_error", "tpr_version", "tpr_solve_batch",
     "tpr_controllable_sets_batch", "tpr_feasible_sets_batch", "tpr_constraint_params_batch",
     "tpr_solve_stagewise_batch", "tpr_lp1d_batch", "tpr_lp2d_batch", "tpr_solve_batch_timed",
-    "tpr_spline_fit_batch",
+    "tpr_spline_fit_batch", "tpr_const_accel_times_batch", "tpr_const_accel_eval_batch",
 )
 
 _lib = None
@@ -103,6 +103,10 @@ def load():
         L.tpr_spline_fit_batch.restype = C.c_int
         L.tpr_spline_fit_batch.argtypes = [C.c_int, C.c_int, C.c_int, V, C.c_int, V, C.c_int, C.c_int, V, V, V,
                                            C.c_int, V]
+        L.tpr_const_accel_times_batch.restype = C.c_int
+        L.tpr_const_accel_times_batch.argtypes = [P, V, V, V, V]
+        L.tpr_const_accel_eval_batch.restype = C.c_int
+        L.tpr_const_accel_eval_batch.argtypes = [P, V, V, V, C.c_int, V, C.c_int, V, V]
         L.tpr_lp1d_batch.restype = C.c_int
         L.tpr_lp1d_batch.argtypes = [C.c_int, C.c_int] + [V] * 10
         L.tpr_lp2d_batch.restype = C.c_int

@@ -15,7 +15,7 @@ from . import _capi
 
 __all__ = ["solve_batch", "controllable_sets_batch", "feasible_sets_batch",
            "constraint_params_batch", "make_synthetic_batch", "spline_coefficients",
-           "spline_fit_batch", "solve_batch_timed"]
+           "spline_fit_batch", "solve_batch_timed", "const_accel_times_batch", "const_accel_eval_batch"]
 
 
 def _stream_ptr(like):
@@ -133,6 +133,38 @@ def spline_coefficients(knots, waypoints, bc_type="not-a-knot"):
     cs = CubicSpline(np.asarray(knots, dtype=np.float64), way.transpose(1, 0, 2), bc_type=bc_type)
     # cs.c: [4, m-1, B, d] -> [B, 4, m-1, d]
     return np.ascontiguousarray(cs.c.transpose(2, 0, 1, 3)), np.asarray(cs.x, dtype=np.float64)
+
+
+def const_accel_times_batch(grid, sd):
+    """ParametrizeConstAccel._process_parametrization for B trajectories: sd [B, N+1] ->
+    (ts [B, N+1], us [B, N])."""
+    _prepare(sd)
+    dev = _capi.is_torch_cuda(sd)
+    conv = (lambda x: x.contiguous()) if dev else _capi.f64
+    sd, grid = conv(sd), conv(grid)
+    B, n1 = (int(v) for v in sd.shape)
+    p = _capi.tpr_problem(B=B, d=1, nseg=1, N=n1 - 1,
+                          flags=(_capi.DEVICE_PTRS if dev else 0) | (_capi.GRID_PER_TRAJ if grid.ndim == 2 else 0))
+    p.grid = _capi.ptr(grid)
+    ts, us = _empty(sd, (B, n1)), _empty(sd, (B, n1 - 1))
+    _capi.check(_capi.load().tpr_const_accel_times_batch(C.byref(p), _capi.ptr(sd), _capi.ptr(ts), _capi.ptr(us),
+                                                         _stream_ptr(sd)))
+    return ts, us
+
+
+def const_accel_eval_batch(coef, breaks, grid, sd, ts, us, times, order=0):
+    """ParametrizeConstAccel.__call__(t, order) for B trajectories: times [B, T] -> [B, T, d]."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, None, None)
+    dev = _capi.is_torch_cuda(coef)
+    conv = (lambda x: x.contiguous()) if dev else _capi.f64
+    sd, ts, us, times = conv(sd), conv(ts), conv(us), conv(times)
+    T = int(times.shape[1])
+    out = _empty(coef, (p.B, T, p.d))
+    _capi.check(_capi.load().tpr_const_accel_eval_batch(C.byref(p), _capi.ptr(sd), _capi.ptr(ts), _capi.ptr(us), T,
+                                                        _capi.ptr(times), int(order), _capi.ptr(out),
+                                                        _stream_ptr(coef)))
+    return out
 
 
 _BC_KINDS = {"not-a-knot": 0, "clamped": 1, "natural": 2}

@@ -14,6 +14,7 @@
 #include "tpr_lane.hip.inc"
 #include "tpr_group.hip.inc"
 #include "tpr_spline.hip.inc"
+#include "tpr_param.hip.inc"
 
 namespace {
 
@@ -313,6 +314,51 @@ int tpr_solve_stagewise_batch(const tpr_problem *p, const int32_t *stage, const 
     if (A.B > 0)
         hipLaunchKernelGGL(tpr::lane_stagewise_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dstage,
                            dg, dxb, dact, solve_lp1d, dout);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_const_accel_times_batch(const tpr_problem *p, const double *sd, double *ts, double *us, void *stream_) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (!p || p->B < 0 || p->N < 1 || !p->grid || !sd || !ts) return fail(TPR_E_BADARG, "bad const-accel arguments");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    tpr::ParamArgs A{};
+    A.B = p->B; A.N = p->N; A.flags = p->flags;
+    A.grid = S.in(p->grid, ((p->flags & TPR_GRID_PER_TRAJ) ? B : 1) * (N + 1));
+    A.sd = S.in(sd, B * (N + 1));
+    A.ts = S.out(ts, B * (N + 1));
+    A.us = S.out(us, B * N);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (A.B > 0) hipLaunchKernelGGL(tpr::const_accel_times_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_const_accel_eval_batch(const tpr_problem *p, const double *sd, const double *ts, const double *us,
+                               int T, const double *times, int order, double *out, void *stream_) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (!p || p->B < 0 || p->N < 1 || p->d < 1 || p->nseg < 1 || !p->coef || !p->breaks || !p->grid || !sd || !ts ||
+        !us || !times || !out || T < 0 || order < 0 || order > 2)
+        return fail(TPR_E_BADARG, "bad const-accel eval arguments");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    const size_t B = (size_t)p->B, N = (size_t)p->N, d = (size_t)p->d, nseg = (size_t)p->nseg;
+    tpr::EvalArgs A{};
+    A.B = p->B; A.N = p->N; A.d = p->d; A.nseg = p->nseg; A.T = T; A.flags = p->flags; A.order = order;
+    A.coef = S.in(p->coef, B * 4 * nseg * d);
+    A.breaks = S.in(p->breaks, ((p->flags & TPR_BREAKS_PER_TRAJ) ? B : 1) * (nseg + 1));
+    A.grid = S.in(p->grid, ((p->flags & TPR_GRID_PER_TRAJ) ? B : 1) * (N + 1));
+    A.sd = S.in(sd, B * (N + 1));
+    A.ts = S.in(ts, B * (N + 1));
+    A.us = S.in(us, B * N);
+    A.times = S.in(times, B * (size_t)T);
+    A.out = S.out(out, B * (size_t)T * d);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    const long long total = (long long)p->B * T;
+    if (total > 0)
+        hipLaunchKernelGGL(tpr::const_accel_eval_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, A);
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
