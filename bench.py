@@ -168,6 +168,8 @@ def main():
     # dominant kernel: average launch duration with HIP events on the launch stream
     kernel_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], out,
                                      reps=args.kernel_reps, variant=args.variant)
+    strict_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], out,
+                                     reps=max(2, args.kernel_reps // 2), variant=args.variant, strict=True)
     ok_frac = float((out["status"] == 0).double().mean().item())
 
     if rank == 0:
@@ -196,6 +198,11 @@ def main():
                 "kernel_variant": args.variant,
             },
             "waypoint_lps_per_s": 3 * N * traj_per_s,
+            "strict_seidel": {
+                "note": "TPR_STRICT_SEIDEL: every lower-bound LP through the full Seidel iteration instead of the "
+                        "certified shortcut (identical bits; single-GPU kernel time only)",
+                "kernel_ms": strict_ms, "value_per_gpu": B / strict_ms * 1e3, "unit": "trajectories/s",
+            },
             "relaxed_mode": {
                 "note": "opt-in TPR_RELAXED_LOWER: backward lower-bound LPs whose answer is provably 0 are "
                         "skipped (~2N instead of 3N LPs per trajectory); NOT the headline value",

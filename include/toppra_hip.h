@@ -48,6 +48,13 @@ extern "C" {
  * Results stay within ~1e-13 of the reference (bound asserted in the tests: 1e-8) instead of being
  * bit-identical.  Honoured by the rows-across-lanes kernels; ignored elsewhere.                    */
 #define TPR_RELAXED_LOWER 64
+/* Force every stage LP through the full Seidel iteration.  By default the rows-across-lanes kernels
+ * answer the backward lower-bound LP from a verified certificate (the optimal vertex is "x on its box
+ * bound, u on the tightest row", checked with margins 1e3..1e4 above the solver's tolerances) and
+ * evaluate the reference's own pivot formulas for that vertex; marginal cases fall back to the full
+ * iteration.  Both give the same bits (cross-checked on ~1e8 stage LPs, tests/test_gpu_fullsize.py);
+ * this flag exists for A/B testing and for callers who want the iteration itself replicated.        */
+#define TPR_STRICT_SEIDEL 128
 
 /* per-trajectory status == ParameterizationReturnCode (algorithm/algorithm.py:49-62) */
 #define TPR_STATUS_OK 0

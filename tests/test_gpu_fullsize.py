@@ -54,3 +54,23 @@ def test_full_size_properties(gpu, oracle, B, d, N):
     v1 = batch.solve_batch(data["coef"][sl], data["breaks"], data["grid"], data["vlim"][sl], data["alim"][sl], variant=1)
     for k in ("K", "sd2", "u", "status"):
         assert np.array_equal(out[k][sl], v1[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("B,d,N,seed", [(65536, 7, 200, 20240924), (32768, 6, 500, 3), (16384, 3, 100, 5),
+                                        (16384, 8, 64, 6), (8192, 1, 50, 8)])
+def test_lower_bound_shortcut_is_exact(gpu, B, d, N, seed):
+    """The certified shortcut of the backward lower-bound LP (default) against the full Seidel
+    iteration (TPR_STRICT_SEIDEL) on every stage of large batches: identical bits, including
+    non-zero boundary velocities and badly scaled paths on which the reference itself fails."""
+    data = batch.make_synthetic_batch(B, d, N, seed=seed)
+    rng = np.random.default_rng(seed)
+    sd0 = np.where(rng.random(B) < 0.3, 0.1 * rng.random(B), 0.0)
+    sd1 = np.where(rng.random(B) < 0.3, 0.3 * rng.random(B), 0.0)
+    scale = 10.0 ** rng.uniform(-6, 0, size=(B, 1, 1, 1))
+    for coef, s0, s1 in ((data["coef"], sd0, sd1), (data["coef"] * scale, None, None)):
+        args = (coef, data["breaks"], data["grid"], data["vlim"], data["alim"], s0, s1)
+        fast = batch.solve_batch(*args)
+        full = batch.solve_batch(*args, strict=True)
+        assert len(np.unique(full["status"])) >= (1 if s0 is not None else 2)
+        for k in ("K", "sd2", "u", "status"):
+            assert np.array_equal(fast[k], full[k], equal_nan=True), k

@@ -20,6 +20,7 @@ DEVICE_PTRS = 8
 BREAKS_PER_TRAJ = 16
 GRID_PER_TRAJ = 32
 RELAXED_LOWER = 64
+STRICT_SEIDEL = 128
 
 STATUS_OK, STATUS_FAIL_UNCONTROLLABLE, STATUS_ERR_UNKNOWN = 0, 1, 2
 
@@ -161,7 +162,7 @@ def ptr(x):
 
 
 def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
-                 variant=0, keep=None, relaxed=False):
+                 variant=0, keep=None, relaxed=False, strict=False):
     """Build a tpr_problem from arrays (all numpy or all torch-CUDA).  `keep` collects the
     converted arrays so they outlive the call."""
     dev = is_torch_cuda(coef)
@@ -174,7 +175,7 @@ def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, int
         raise ValueError("coef must have shape [B, 4, nseg, d]")
     B, _, nseg, d = (int(s) for s in coef.shape)
     N = int(grid.shape[-1]) - 1
-    flags = (DEVICE_PTRS if dev else 0) | (RELAXED_LOWER if relaxed else 0)
+    flags = (DEVICE_PTRS if dev else 0) | (RELAXED_LOWER if relaxed else 0) | (STRICT_SEIDEL if strict else 0)
     if breaks.ndim == 2:
         flags |= BREAKS_PER_TRAJ
     if grid.ndim == 2:

@@ -42,17 +42,18 @@ def _prepare(coef):
 
 
 def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
-                want_sd=False, variant=0, relaxed=False):
+                want_sd=False, variant=0, relaxed=False, strict=False):
     """compute_parameterization for B trajectories.
 
     Returns dict(sd2[B,N+1], u[B,N], K[B,N+1,2], status[B] (+ sd[B,N+1] if want_sd)); failed
     trajectories are NaN-filled with status 1 (FailUncontrollable) or 2 (ErrUnknown).
 
     ``relaxed=True`` (TPR_RELAXED_LOWER) skips backward lower-bound LPs whose answer is provably 0;
-    results then agree with the reference to ~1e-13 instead of bit for bit."""
+    results then agree with the reference to ~1e-13 instead of bit for bit.  ``strict=True``
+    (TPR_STRICT_SEIDEL) disables the certified shortcut of the lower-bound LP (same bits, slower)."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
-                                 variant, relaxed=relaxed)
+                                 variant, relaxed=relaxed, strict=strict)
     B, N = p.B, p.N
     out = {"sd2": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)),
            "K": _empty(coef, (B, N + 1, 2)), "status": _empty(coef, (B,), "i32")}
@@ -65,12 +66,12 @@ def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, inte
 
 
 def solve_batch_timed(coef, breaks, grid, vlim, alim, out, reps, sd_start=None, sd_end=None,
-                      interpolation=True, variant=0, relaxed=False):
+                      interpolation=True, variant=0, relaxed=False, strict=False):
     """bench.py helper: `reps` launches between two hipEvents on torch's current stream.
     Returns average ms per launch.  `out` is a dict from a previous solve_batch (device)."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
-                                 variant, relaxed=relaxed)
+                                 variant, relaxed=relaxed, strict=strict)
     r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out["u"]),
                          K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
     ms = C.c_float(0)
