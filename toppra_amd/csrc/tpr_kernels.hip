@@ -116,17 +116,22 @@ size_t group_lds_bytes(int nseg, int threads) {
     return (size_t)(threads / L) * tpr::GroupCfg<D, L>::lds_doubles(nseg) * sizeof(double);
 }
 
-// Largest block (256, 128 or 64 threads) whose LDS staging area fits; 0 when none does.
+// Block size: the largest of 256 / 128 / 64 threads whose LDS staging area fits, shrunk further
+// while the batch would leave CUs idle (a block is one CU's worth of work; 256 CUs, and small
+// batches such as BASELINE config 2's 4096 trajectories only make 128 blocks of 256 threads).
+// 0 when even a single wave does not fit.
 template <int D, int L>
-int group_block_threads(int nseg) {
-    for (int threads = 256; threads >= 64; threads /= 2)
-        if (group_lds_bytes<D, L>(nseg, threads) <= kMaxDynamicLds) return threads;
-    return 0;
+int group_block_threads(int nseg, int B) {
+    int threads = 0;
+    for (int t = 256; t >= 64; t /= 2)
+        if (group_lds_bytes<D, L>(nseg, t) <= kMaxDynamicLds) { threads = t; break; }
+    while (threads > 64 && (long long)B * L / threads < 4 * 256) threads /= 2;
+    return threads;
 }
 
 template <int D, int L>
 int launch_group(const tpr::BatchArgs &A, hipStream_t stream) {
-    const int threads = group_block_threads<D, L>(A.nseg);
+    const int threads = group_block_threads<D, L>(A.nseg, A.B);
     if (threads == 0) return fail(TPR_E_UNSUPPORTED, "spline table too large for the LDS staging area");
     tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
                      A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
