@@ -62,3 +62,29 @@ def test_collocation_and_single_constraint(gpu, oracle):
     ref = oracle.solve_batch(data["coef"], data["breaks"], data["grid"], None, data["alim"],
                              flags=FLAG_ACC | 4)
     _compare(got, ref)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("B,d,N,nway", [(9, 2, 1, 2), (17, 3, 2, 3), (33, 7, 3, 2), (64, 1, 5, 4), (1, 7, 200, 5),
+                                        (31, 8, 7, 9), (257, 6, 33, 6)])
+def test_edge_shapes(gpu, oracle, B, d, N, nway, variant):
+    """Smallest grids (N = 1), one spline segment, single trajectory, ragged batch sizes."""
+    data = batch.make_synthetic_batch(B, d, N, seed=B + N, n_waypoints=nway)
+    got = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], variant=variant)
+    ref = oracle.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    _compare(got, ref)
+
+
+def test_empty_batch_and_bad_arguments(gpu):
+    data = batch.make_synthetic_batch(4, 3, 10)
+    out = batch.solve_batch(data["coef"][:0], data["breaks"], data["grid"], data["vlim"][:0], data["alim"][:0])
+    assert out["sd2"].shape == (0, 11) and out["status"].shape == (0,)
+    from toppra_amd import _capi
+    with pytest.raises(_capi.ToppraHipError):  # d > TPR_MAX_DOF
+        big = batch.make_synthetic_batch(2, 17, 10)
+        batch.solve_batch(big["coef"], big["breaks"], big["grid"], big["vlim"], big["alim"])
+    with pytest.raises(_capi.ToppraHipError):  # the fast kernel refuses Collocation when forced
+        batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"],
+                          interpolation=False, variant=2)
+    big = batch.make_synthetic_batch(8, 12, 20)  # d > 8 runs on the generic kernel
+    assert batch.solve_batch(big["coef"], big["breaks"], big["grid"], big["vlim"], big["alim"])["status"].shape == (8,)
