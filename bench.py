@@ -172,7 +172,7 @@ def main():
     # dominant kernel: average launch duration with HIP events on the launch stream
     kernel_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], out,
                                      reps=args.kernel_reps, variant=args.variant)
-    strict_ms = float("nan")
+    strict_ms = None
     if not args.no_secondary:
         strict_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], out,
                                          reps=max(2, args.kernel_reps // 2), variant=args.variant, strict=True)
@@ -208,7 +208,8 @@ def main():
             "strict_seidel": {
                 "note": "TPR_STRICT_SEIDEL: every lower-bound LP through the full Seidel iteration instead of the "
                         "certified shortcut (identical bits; single-GPU kernel time only)",
-                "kernel_ms": strict_ms, "value_per_gpu": B / strict_ms * 1e3, "unit": "trajectories/s",
+                "kernel_ms": strict_ms, "value_per_gpu": (B / strict_ms * 1e3) if strict_ms else None,
+                "unit": "trajectories/s",
             },
             "relaxed_mode": {
                 "note": "opt-in TPR_RELAXED_LOWER: backward lower-bound LPs whose answer is provably 0 are "
