@@ -83,8 +83,23 @@ def test_empty_batch_and_bad_arguments(gpu):
     with pytest.raises(_capi.ToppraHipError):  # d > TPR_MAX_DOF
         big = batch.make_synthetic_batch(2, 17, 10)
         batch.solve_batch(big["coef"], big["breaks"], big["grid"], big["vlim"], big["alim"])
+    wide = batch.make_synthetic_batch(8, 12, 20)  # d > 8: 16 lanes per trajectory
+    assert batch.solve_batch(wide["coef"], wide["breaks"], wide["grid"], wide["vlim"], wide["alim"],
+                             variant=2)["status"].shape == (8,)
     with pytest.raises(_capi.ToppraHipError):  # the fast kernel refuses Collocation when forced
         batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"],
                           interpolation=False, variant=2)
-    big = batch.make_synthetic_batch(8, 12, 20)  # d > 8 runs on the generic kernel
-    assert batch.solve_batch(big["coef"], big["breaks"], big["grid"], big["vlim"], big["alim"])["status"].shape == (8,)
+
+
+@pytest.mark.parametrize("B,d,N,nway", [(40, 9, 50, 5), (33, 12, 64, 6), (20, 16, 40, 5), (64, 14, 100, 4),
+                                        (24, 7, 120, 40), (16, 3, 300, 120), (12, 16, 60, 64)])
+def test_wide_dof_and_long_splines(gpu, oracle, B, d, N, nway):
+    """d = 9..16 run with 16 lanes per trajectory; paths with many spline segments keep the
+    coefficient table in global memory instead of LDS.  Both against the oracle, both families."""
+    data = batch.make_synthetic_batch(B, d, N, seed=d * 100 + nway, n_waypoints=nway)
+    ref = oracle.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    for variant in (1, 2):
+        got = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], variant=variant)
+        _compare(got, ref)
+    strict = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], strict=True)
+    _compare(strict, ref)

@@ -112,42 +112,39 @@ tpr::BatchArgs stage_problem(const tpr_problem *p, Staging &S) {
 constexpr size_t kMaxDynamicLds = 64 * 1024;
 
 template <int D, int L>
-size_t group_lds_bytes(int nseg, int threads) {
-    return (size_t)(threads / L) * tpr::GroupCfg<D, L>::lds_doubles(nseg) * sizeof(double);
+size_t group_lds_bytes(int nseg, int threads, bool table_in_lds) {
+    return (size_t)(threads / L) * tpr::GroupCfg<D, L>::lds_doubles(nseg, table_in_lds) * sizeof(double);
 }
 
-// Block size: the largest of 256 / 128 / 64 threads whose LDS staging area fits, shrunk further
-// while the batch would leave CUs idle (a block is one CU's worth of work; 256 CUs, and small
-// batches such as BASELINE config 2's 4096 trajectories only make 128 blocks of 256 threads).
-// 0 when even a single wave does not fit.
-template <int D, int L>
-int group_block_threads(int nseg, int B) {
-    int threads = 0;
-    for (int t = 256; t >= 64; t /= 2)
-        if (group_lds_bytes<D, L>(nseg, t) <= kMaxDynamicLds) { threads = t; break; }
-    while (threads > 64 && (long long)B * L / threads < 4 * 256) threads /= 2;
-    return threads;
-}
-
+// Launch geometry of the rows-across-lanes kernel.  The spline table is staged in LDS when a
+// 64-thread block's worth fits in 64 KB (always for ordinary waypoint counts); otherwise it stays
+// in global memory.  Block size: the largest of 256 / 128 / 64 threads that fits, shrunk further
+// while the batch would leave CUs idle (256 CUs; small batches such as BASELINE config 2's 4096
+// trajectories only make 128 blocks of 256 threads).
 template <int D, int L>
 int launch_group(const tpr::BatchArgs &A, hipStream_t stream) {
-    const int threads = group_block_threads<D, L>(A.nseg, A.B);
-    if (threads == 0) return fail(TPR_E_UNSUPPORTED, "spline table too large for the LDS staging area");
+    const bool table_in_lds = group_lds_bytes<D, L>(A.nseg, 64, true) <= kMaxDynamicLds;
+    int threads = 64;
+    for (int t = 256; t > 64; t /= 2)
+        if (group_lds_bytes<D, L>(A.nseg, t, table_in_lds) <= kMaxDynamicLds) { threads = t; break; }
+    while (threads > 64 && (long long)A.B * L / threads < 4 * 256) threads /= 2;
     tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
                      A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
     const int groups = threads / L;
-    const size_t lds = group_lds_bytes<D, L>(A.nseg, threads);
-    hipLaunchKernelGGL((tpr::group_solve_kernel<D, L>), dim3((A.B + groups - 1) / groups), dim3(threads), lds,
-                       stream, G);
+    size_t lds = group_lds_bytes<D, L>(A.nseg, threads, table_in_lds);
+    if (const char *pad = std::getenv("TPR_LDS_PAD")) lds += (size_t)std::atoi(pad);  // occupancy experiments
+    const dim3 grid((A.B + groups - 1) / groups), block(threads);
+    if (table_in_lds) hipLaunchKernelGGL((tpr::group_solve_kernel<D, L, true>), grid, block, lds, stream, G);
+    else hipLaunchKernelGGL((tpr::group_solve_kernel<D, L, false>), grid, block, lds, stream, G);
     return TPR_E_OK;
 }
 
 // The rows-across-lanes kernels cover the reference's default constraint set (acceleration with
-// Interpolation, velocity optional) for d <= 8 and spline tables that fit the LDS staging area.
+// Interpolation, velocity optional) for every supported dof: 8 lanes per trajectory up to d = 8,
+// 16 lanes above.
 bool group_supported(const tpr::BatchArgs &A) {
     const int need = TPR_HAS_ACCELERATION | TPR_ACC_INTERPOLATION;
-    if ((A.flags & need) != need || A.d < 1 || A.d > 8) return false;
-    return (size_t)(64 / 8) * (3 * A.nseg * A.d + A.nseg + 1 + 3 * (6 + 4 * A.d)) * 8 <= kMaxDynamicLds;
+    return (A.flags & need) == need && A.d >= 1 && A.d <= TPR_MAX_DOF;
 }
 
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
@@ -156,7 +153,7 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
     if (variant == 0) variant = group_supported(A) ? 2 : 1;
     switch (variant) {
         case 2: {
-            if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 2 needs acceleration+interpolation, d <= 8");
+            if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 2 needs acceleration+interpolation");
             switch (A.d) {
                 case 1: return launch_group<1, 8>(A, stream);
                 case 2: return launch_group<2, 8>(A, stream);
@@ -166,6 +163,14 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
                 case 6: return launch_group<6, 8>(A, stream);
                 case 7: return launch_group<7, 8>(A, stream);
                 case 8: return launch_group<8, 8>(A, stream);
+                case 9: return launch_group<9, 16>(A, stream);
+                case 10: return launch_group<10, 16>(A, stream);
+                case 11: return launch_group<11, 16>(A, stream);
+                case 12: return launch_group<12, 16>(A, stream);
+                case 13: return launch_group<13, 16>(A, stream);
+                case 14: return launch_group<14, 16>(A, stream);
+                case 15: return launch_group<15, 16>(A, stream);
+                case 16: return launch_group<16, 16>(A, stream);
             }
             return TPR_E_OK;
         }
