@@ -146,3 +146,18 @@ def test_batch_toppra_and_torch_device_path(gpu):
     br2 = np.tile(fx["breaks"], (fx["coef"].shape[0], 1))
     out3 = ta.batch.solve_batch(fx["coef"], br2, grid2, fx["vlim"], fx["alim"], want_sd=True, variant=1)
     assert_same(out3["sd"], fx["sd"], "sd (per-trajectory breaks)")
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_robust_constraint_params(gpu, example, scheme):
+    """RobustLinearConstraint.compute_constraint_params vs the reference's output."""
+    fx, path, pc_vel, pc_acc = example
+    rc = ta.constraint.RobustLinearConstraint(ta.constraint.JointAccelerationConstraint(fx["alim"][0]),
+                                              [1e-3, 5e-2, 9e-3], scheme)
+    a, b, c, P, ub, xb = rc.compute_constraint_params(path, fx["n100_grid"])
+    assert_same(a, fx["robust%d_a" % scheme], "a"); assert_same(b, fx["robust%d_b" % scheme], "b")
+    assert_same(c, fx["robust%d_c" % scheme], "c"); assert_same(P, fx["robust%d_P" % scheme], "P")
+    assert ub is None and xb is None
+    assert rc.get_constraint_type() == ta.constraint.ConstraintType.CanonicalConic
+    with pytest.raises(ta.exceptions.ToppraError):  # no conic solver in this build (reference: needs ecos)
+        ta.algorithm.TOPPRA([pc_vel, rc], path, gridpoints=fx["n100_grid"])

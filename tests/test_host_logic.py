@@ -118,3 +118,12 @@ def test_parametrizers_match_reference_outputs(example):
     assert sp.duration == float(fx["spl_duration"])
     for order in (0, 1, 2):
         np.testing.assert_allclose(sp(fx["spl_times"], order), fx["spl_q%d" % order], rtol=1e-12, atol=1e-11)
+
+
+def test_robust_constraint_validation():
+    acc = ta.constraint.JointAccelerationConstraint([1.0, 2.0])
+    with pytest.raises(ValueError):
+        ta.constraint.RobustLinearConstraint(acc, [1e-3, -1.0, 0.0])
+    rc = ta.constraint.RobustLinearConstraint(acc, [0.1, 0.2, 0.3], 1)
+    assert rc.get_dof() == 2 and rc.get_discretization_type() == ta.constraint.DiscretizationType.Interpolation
+    assert rc.get_constraint_type() == ta.constraint.ConstraintType.CanonicalConic

@@ -141,6 +141,13 @@ def example_fixture():
             out["spl_times"] = ts2
             for order in (0, 1, 2):
                 out["spl_q%d" % order] = sp(ts2, order)
+            # robust constraint parameters (conic_constraint.py:95-124), both discretisations
+            for scheme in (0, 1):
+                rc = constraint.RobustLinearConstraint(constraint.JointAccelerationConstraint(al),
+                                                       [1e-3, 5e-2, 9e-3], scheme)
+                ra, rb, rcc, rP, _, _ = rc.compute_constraint_params(path, grid)
+                out["robust%d_a" % scheme], out["robust%d_b" % scheme] = ra, rb
+                out["robust%d_c" % scheme], out["robust%d_P" % scheme] = rcc, rP
             # stagewise solves on a fresh wrapper, the reference's own call sequence preserved
             from toppra.solverwrapper.cy_seidel_solverwrapper import seidelWrapper
             for lp1d in (0, 1):

@@ -146,3 +146,53 @@ class JointAccelerationConstraint(LinearConstraint):
         F[:2 * d, :d] = eye
         F[2 * d:, d:] = eye
         return a, b, np.zeros_like(a), F, np.concatenate([g1, g1]), None, None
+
+
+class ConicConstraint(Constraint):
+    """Base class of canonical conic constraints (conic_constraint.py:6-44)."""
+
+    def __init__(self):
+        self.constraint_type = ConstraintType.CanonicalConic
+        self.discretization_type = DiscretizationType.Collocation
+        self.n_extra_vars = 0
+        self.dof = -1
+        self._format_string = ""
+
+
+class RobustLinearConstraint(ConicConstraint):
+    """Robustified canonical linear constraint (conic_constraint.py:47-124):
+    ``a u + b x + c + ||diag(ru, rx, rc) [u, x, 1]||_2 <= 0`` for every row of the base constraint.
+
+    ``compute_constraint_params`` returns the reference's 6-tuple
+    ``(a, b, c, P, ubound, xbound)``; the rows come from the HIP library.  Solving the resulting
+    second-order-cone stage problems needs the reference's ECOS back-end, which this build does not
+    replace: constructing a TOPPRA instance with a conic constraint raises ``ToppraError`` exactly
+    as the reference does when ecos is not installed (reachability_algorithm.py:66-70).
+    """
+
+    def __init__(self, cnst, ellipsoid_axes_lengths, discretization_scheme=DiscretizationType.Collocation):
+        super(RobustLinearConstraint, self).__init__()
+        self.dof = cnst.get_dof()
+        assert getattr(cnst.get_constraint_type(), "value", None) == 0  # CanonicalLinear
+        self.set_discretization_type(discretization_scheme)
+        if np.any(np.r_[ellipsoid_axes_lengths] < 0):
+            raise ValueError("Perturbation must be non-negative. Input {:}".format(ellipsoid_axes_lengths))
+        self.base_constraint = cnst
+        self.ellipsoid_axes_lengths = ellipsoid_axes_lengths
+        self._format_string += "    Robust constraint generated from a canonical linear constraint\n"
+
+    def compute_constraint_params(self, path, gridpoints):
+        base = self.base_constraint
+        base.set_discretization_type(self.discretization_type)  # the reference mutates the base too
+        if not hasattr(base, "alim"):
+            raise NotImplementedError("robustification of %s is outside the HIP path" % type(base).__name__)
+        _check_dof(base, path)
+        interp = self.discretization_type == DiscretizationType.Interpolation
+        out = _params_on_device(path, gridpoints, alim=np.ascontiguousarray(base.alim, dtype=np.float64),
+                                interpolation=interp)
+        # F a, F b, F c - g are the wrapper's dense rows 2.. (cy_seidel_solverwrapper.pyx:490-499)
+        a, b, c = (np.array(out[k][0][:, 2:]) for k in ("a", "b", "c"))
+        rows = a.shape[1]
+        P = np.zeros((len(gridpoints), rows + 2, 3, 3))
+        P[:] = np.diag(self.ellipsoid_axes_lengths)
+        return a, b, c, P, None, None
