@@ -101,6 +101,15 @@ const char *tpr_version(void);
  * compute_constraint_params (cy_seidel_solverwrapper.pyx:425-531) which is fused in.            */
 int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream);
 
+/* Replaces TOPPRAsd.compute_parameterization (algorithm/reachabilitybased/
+ * desired_duration_algorithm.py:42-234) for B trajectories: the backward scan, the "fastest" and
+ * "slowest" forward scans, the duration bisection on their convex combination (absolute tolerance
+ * atol, reference default 1e-5) and the blended sd^2 / u.  desired [B] seconds; alpha [B] (may be
+ * NULL) receives the blend factor.  Same result struct and status codes as tpr_solve_batch.
+ * Needs the rows-across-lanes kernels (acceleration constraint with Interpolation).                */
+int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired, double atol,
+                                     const tpr_result *r, double *alpha, void *stream);
+
 /* Replaces ReachabilityAlgorithm.compute_controllable_sets(sdmin, sdmax)
  * (reachability_algorithm.py:166-238).  sdmin/sdmax [B]; K [B][N+1][2].                          */
 int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const double *sdmax,

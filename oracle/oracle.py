@@ -67,6 +67,13 @@ def lib():
         L.orc_solve_batch.restype = C.c_int
         L.orc_solve_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, C.c_int,
                                       dp, dp, dp, dp, C.c_int, dp, dp, dp, C.POINTER(C.c_int32), C.c_int]
+        L.orc_compute_parameterization_sd.restype = C.c_int
+        L.orc_compute_parameterization_sd.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
+                                                      dp, dp, dp, dp, dp]
+        L.orc_solve_batch_sd.restype = C.c_int
+        L.orc_solve_batch_sd.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp, dp,
+                                         dp, dp, dp, C.c_double, C.c_int, dp, dp, dp, C.POINTER(C.c_int32), dp,
+                                         C.c_int]
         for name in ("a", "b", "c", "low", "high"):
             f = getattr(L, "orc_wrapper_" + name)
             f.restype = dp
@@ -209,6 +216,26 @@ class Wrapper:
         st = lib().orc_compute_parameterization(self._h, sd_start, sd_end, _dp(sdd), _dp(sd),
                                                 _dp(xs), _dp(K))
         return st, sdd, sd, xs, K
+
+
+def solve_batch_sd(coef, breaks, grid, vlim, alim, desired_duration, sd_start=None, sd_end=None, atol=1e-5,
+                   flags=DEFAULT_FLAGS, nthreads=1):
+    """TOPPRAsd batch driver: dict(sd2, u, K, status, alpha)."""
+    coef, breaks, grid = _f64(coef), _f64(breaks), _f64(grid)
+    B, _, nseg, d = coef.shape
+    N = grid.shape[-1] - 1
+    vlim = _f64(vlim) if vlim is not None else None
+    alim = _f64(alim) if alim is not None else None
+    sd_start = _f64(sd_start) if sd_start is not None else None
+    sd_end = _f64(sd_end) if sd_end is not None else None
+    desired = _f64(np.broadcast_to(desired_duration, (B,)))
+    sd2, u, K = np.zeros((B, N + 1)), np.zeros((B, N)), np.zeros((B, N + 1, 2))
+    status, alpha = np.zeros(B, dtype=np.int32), np.zeros(B)
+    lib().orc_solve_batch_sd(B, d, nseg, N, _dp(coef), _dp(breaks), int(breaks.ndim == 2), _dp(grid),
+                             int(grid.ndim == 2), _dp(vlim), _dp(alim), _dp(sd_start), _dp(sd_end), _dp(desired),
+                             float(atol), flags, _dp(sd2), _dp(u), _dp(K), status.ctypes.data_as(C.POINTER(C.c_int32)),
+                             _dp(alpha), int(nthreads))
+    return {"sd2": sd2, "u": u, "K": K, "status": status, "alpha": alpha}
 
 
 def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, flags=DEFAULT_FLAGS,

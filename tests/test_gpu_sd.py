@@ -1,0 +1,47 @@
+"""TOPPRAsd (desired duration) on the GPU vs the reference's outputs (tests/golden) and the oracle."""
+import numpy as np
+import pytest
+
+import toppra_amd as ta
+from tests.helpers import assert_same, golden
+from toppra_amd import batch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sd_fixture(gpu):
+    fx = golden("sd_batch_d5_N80")
+    out = batch.solve_desired_duration_batch(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"],
+                                             fx["desired"], fx["sd_start"], fx["sd_end"])
+    assert np.array_equal(out["status"], fx["status"]) and set(fx["status"]) == {0, 1}
+    assert_same(out["K"], fx["K"], "K")
+    assert_same(out["sd"], fx["sd"], "sd")
+    assert_same(out["u"], fx["u"], "u")
+    ok = fx["status"] == 0
+    assert np.any(out["alpha"][ok] == 1.0) and np.any((out["alpha"][ok] > 0) & (out["alpha"][ok] < 1))
+
+
+def test_sd_class_and_oracle(gpu, oracle):
+    data = batch.make_synthetic_batch(96, 7, 60, seed=12)
+    rng = np.random.default_rng(2)
+    fast = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], want_sd=True)
+    ts, _ = batch.const_accel_times_batch(data["grid"], fast["sd"])
+    desired = ts[:, -1] * rng.choice([0.7, 1.3, 2.5, 50.0], size=96)
+    args = (data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], desired)
+    got = batch.solve_desired_duration_batch(*args)
+    ref = oracle.solve_batch_sd(*args)
+    assert np.array_equal(got["status"], ref["status"])
+    assert_same(got["sd2"], ref["sd2"], "sd2"); assert_same(got["u"], ref["u"], "u"); assert_same(got["alpha"], ref["alpha"], "alpha")
+    # achieved durations hit the target within the bisection tolerance where it is reachable
+    ts2, _ = batch.const_accel_times_batch(data["grid"], got["sd"])
+    mid = (got["alpha"] > 0) & (got["alpha"] < 1)
+    assert mid.any() and np.all(np.abs(ts2[mid, -1] - desired[mid]) < 1e-3)
+    # drop-in class
+    b = 3
+    path = ta.SplineInterpolator(data["knots"], data["waypoints"][b])
+    inst = ta.algorithm.TOPPRAsd([ta.constraint.JointVelocityConstraint(data["vlim"][b]),
+                                  ta.constraint.JointAccelerationConstraint(data["alim"][b])], path,
+                                 gridpoints=data["grid"])
+    inst.set_desired_duration(float(desired[b]))
+    sdd, sd, _ = inst.compute_parameterization(0, 0)
+    assert_same(sd, got["sd"][b], "sd_vec"); assert_same(sdd, got["u"][b], "sdd_vec")

@@ -79,3 +79,14 @@ def test_random_lps(oracle):
         assert res == fx["result1"][t]
         if res:
             assert val == fx["optval1"][t] and var == fx["optvar1"][t] and ac == fx["active1"][t]
+
+
+def test_sd_fixture_oracle(oracle):
+    """TOPPRAsd restatement (oracle) vs the reference's outputs."""
+    fx = golden("sd_batch_d5_N80")
+    out = oracle.solve_batch_sd(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"], fx["desired"],
+                                fx["sd_start"], fx["sd_end"])
+    assert np.array_equal(out["status"], fx["status"])
+    assert_same(out["K"], fx["K"], "K")
+    assert_same(np.sqrt(out["sd2"]), fx["sd"], "sd")
+    assert_same(out["u"], fx["u"], "u")

@@ -176,6 +176,39 @@ def example_fixture():
     print("example_kinematics_seed9: N auto =", len(out["auto_grid"]) - 1, "status", out["n100_status"], out["auto_status"])
 
 
+def sd_fixture():
+    """TOPPRAsd (desired_duration_algorithm.py) on random problems: unachievably short, in-range and
+    unachievably long desired durations, some with boundary velocities."""
+    rng = np.random.default_rng(31)
+    B, d, N = 24, 5, 80
+    way = rng.standard_normal((B, 5, d))
+    vmax = 10 + 20 * rng.random((B, d)); amax = 10 + 2 * rng.random((B, d))
+    knots = np.linspace(0, 1, 5); grid = np.linspace(0, 1, N + 1)
+    sd0 = np.where(np.arange(B) % 4 == 1, 0.05, 0.0); sd1 = np.where(np.arange(B) % 4 == 2, 0.03, 0.0)
+    sd0[5] = 9.0  # uncontrollable
+    recs = {k: [] for k in ("coef", "K", "sd", "u", "status", "desired")}
+    for b in range(B):
+        vl = np.stack([-vmax[b], vmax[b]], 1); al = np.stack([-amax[b], amax[b]], 1)
+        path = ta.SplineInterpolator(knots, way[b])
+        cons = [constraint.JointVelocityConstraint(vl), constraint.JointAccelerationConstraint(al)]
+        fast = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_trajectory()
+        base = fast.duration if fast is not None else 1.0
+        desired = float(base * [0.5, 1.2, 1.7, 3.0, 10.0, 1e4][b % 6])
+        inst = algo.TOPPRAsd(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        inst.set_desired_duration(desired)
+        sdd, sd, _, K = inst.compute_parameterization(sd0[b], sd1[b], return_data=True)
+        st = STATUS[inst.problem_data.return_code]
+        if sd is None:
+            sd = np.full(N + 1, np.nan); sdd = np.full(N, np.nan)
+        recs["coef"].append(np.asarray(path.cspl.c)); recs["K"].append(K); recs["sd"].append(sd)
+        recs["u"].append(sdd); recs["status"].append(st); recs["desired"].append(desired)
+    np.savez_compressed(os.path.join(OUT, "sd_batch_d5_N80.npz"), coef=np.stack(recs["coef"]), breaks=knots, grid=grid,
+                        vlim=np.stack([-vmax, vmax], -1), alim=np.stack([-amax, amax], -1), sd_start=sd0, sd_end=sd1,
+                        desired=np.array(recs["desired"]), K=np.stack(recs["K"]), sd=np.stack(recs["sd"]),
+                        u=np.stack(recs["u"]), status=np.array(recs["status"], dtype=np.int32))
+    print("sd_batch_d5_N80 status counts", np.bincount(recs["status"], minlength=3))
+
+
 def cpp_fixture():
     """cpp/tests/test_algorithm.cpp:25-58 scenario (2 dof, Collocation, 51 gridpoints) solved by
     the Python seidel path; the C++ test's own 8-digit vectors are restated in
@@ -241,6 +274,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     example_fixture()
     cpp_fixture()
+    sd_fixture()
     lp_fixture()
     batch_fixture("batch_d7_N200", 32, 7, 200, seed=20240924)
     batch_fixture("batch_d6_N500", 8, 6, 500, seed=20240925)

@@ -179,6 +179,32 @@ class TOPPRA(ReachabilityAlgorithm):
     """
 
 
+class TOPPRAsd(ReachabilityAlgorithm):
+    """TOPP-RA with a specified duration (desired_duration_algorithm.py:21-234): the fastest and the
+    slowest parameterizations are computed and a convex combination with the desired duration is
+    found by bisection.  Unachievable durations return the fastest / slowest one, as the reference."""
+
+    def set_desired_duration(self, desired_duration):
+        self.desired_duration = desired_duration
+
+    def compute_parameterization(self, sd_start, sd_end, return_data=False, atol=1e-5):
+        assert sd_end >= 0 and sd_start >= 0, "Path velocities must be positive"
+        out = self.solver_wrapper.parameterization_sd(sd_start, sd_end, self.desired_duration, atol)
+        K = np.array(out["K"])
+        status = int(out["status"])
+        self._problem_data.return_code = _STATUS_TO_CODE[status]
+        if status == 1:
+            if not np.isnan(K).any():
+                self._problem_data.K = K
+            return (None, None, None, K) if return_data else (None, None, None)
+        self._problem_data.K = K
+        sd_vec, sdd_vec = np.array(out["sd"]), np.array(out["u"])
+        v_vec = np.zeros((self._N, 0))
+        self._problem_data.sd_vec = sd_vec
+        self._problem_data.sdd_vec = sdd_vec
+        return (sdd_vec, sd_vec, v_vec, K) if return_data else (sdd_vec, sd_vec, v_vec)
+
+
 class BatchTOPPRA(object):
     """B independent TOPP-RA problems of one shape solved in one launch.
 
@@ -217,6 +243,11 @@ class BatchTOPPRA(object):
         return _batch.solve_batch(self.coef, self.breaks, self.gridpoints, self.vlim, self.alim,
                                   sd_start, sd_end, self.interpolation, want_sd=want_sd, variant=variant,
                                   relaxed=relaxed)
+
+    def compute_parameterization_sd(self, desired_duration, sd_start=None, sd_end=None, atol=1e-5):
+        """TOPPRAsd for the batch: dict(sd2, sd, u, K, status, alpha)."""
+        return _batch.solve_desired_duration_batch(self.coef, self.breaks, self.gridpoints, self.vlim, self.alim,
+                                                   desired_duration, sd_start, sd_end, atol)
 
     def compute_controllable_sets(self, sdmin, sdmax):
         return _batch.controllable_sets_batch(self.coef, self.breaks, self.gridpoints, self.vlim,

@@ -15,7 +15,8 @@ from . import _capi
 
 __all__ = ["solve_batch", "controllable_sets_batch", "feasible_sets_batch",
            "constraint_params_batch", "make_synthetic_batch", "spline_coefficients",
-           "spline_fit_batch", "solve_batch_timed", "const_accel_times_batch", "const_accel_eval_batch"]
+           "spline_fit_batch", "solve_batch_timed", "const_accel_times_batch", "const_accel_eval_batch",
+           "solve_desired_duration_batch"]
 
 
 def _stream_ptr(like):
@@ -62,6 +63,30 @@ def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, inte
     r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out["u"]),
                          K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
     _capi.check(_capi.load().tpr_solve_batch(C.byref(p), C.byref(r), _stream_ptr(coef)))
+    return out
+
+
+def solve_desired_duration_batch(coef, breaks, grid, vlim, alim, desired_duration, sd_start=None, sd_end=None,
+                                 atol=1e-5):
+    """TOPPRAsd.compute_parameterization for B trajectories (desired_duration_algorithm.py:42-191).
+
+    ``desired_duration``: scalar or [B] seconds.  Returns dict(sd2, sd, u, K, status, alpha): alpha is
+    the blend between the fastest (1) and slowest (0) parameterizations found by bisection."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, True)
+    B, N = p.B, p.N
+    dev = _capi.is_torch_cuda(coef)
+    if dev:
+        import torch
+        desired = torch.as_tensor(desired_duration, dtype=torch.float64, device=coef.device).expand(B).contiguous()
+    else:
+        desired = np.ascontiguousarray(np.broadcast_to(np.asarray(desired_duration, dtype=np.float64), (B,)))
+    out = {"sd2": _empty(coef, (B, N + 1)), "sd": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)),
+           "K": _empty(coef, (B, N + 1, 2)), "status": _empty(coef, (B,), "i32"), "alpha": _empty(coef, (B,))}
+    r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out["sd"]), u=_capi.ptr(out["u"]),
+                         K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
+    _capi.check(_capi.load().tpr_solve_desired_duration_batch(C.byref(p), _capi.ptr(desired), float(atol), C.byref(r),
+                                                              _capi.ptr(out["alpha"]), _stream_ptr(coef)))
     return out
 
 

@@ -147,6 +147,43 @@ bool group_supported(const tpr::BatchArgs &A) {
     return (A.flags & need) == need && A.d >= 1 && A.d <= TPR_MAX_DOF;
 }
 
+template <int D, int L>
+int launch_sd_forward(const tpr::SdArgs &A, hipStream_t stream) {
+    const bool table_in_lds = group_lds_bytes<D, L>(A.nseg, 64, true) <= kMaxDynamicLds;
+    int threads = 64;
+    for (int t = 256; t > 64; t /= 2)
+        if (group_lds_bytes<D, L>(A.nseg, t, table_in_lds) <= kMaxDynamicLds) { threads = t; break; }
+    while (threads > 64 && (long long)A.B * L / threads < 4 * 256) threads /= 2;
+    const int groups = threads / L;
+    const size_t lds = group_lds_bytes<D, L>(A.nseg, threads, table_in_lds);
+    const dim3 grid((A.B + groups - 1) / groups), block(threads);
+    if (table_in_lds) hipLaunchKernelGGL((tpr::group_sd_forward_kernel<D, L, true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((tpr::group_sd_forward_kernel<D, L, false>), grid, block, lds, stream, A);
+    return TPR_E_OK;
+}
+
+int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
+    switch (d) {
+        case 1: return launch_sd_forward<1, 8>(A, stream);
+        case 2: return launch_sd_forward<2, 8>(A, stream);
+        case 3: return launch_sd_forward<3, 8>(A, stream);
+        case 4: return launch_sd_forward<4, 8>(A, stream);
+        case 5: return launch_sd_forward<5, 8>(A, stream);
+        case 6: return launch_sd_forward<6, 8>(A, stream);
+        case 7: return launch_sd_forward<7, 8>(A, stream);
+        case 8: return launch_sd_forward<8, 8>(A, stream);
+        case 9: return launch_sd_forward<9, 16>(A, stream);
+        case 10: return launch_sd_forward<10, 16>(A, stream);
+        case 11: return launch_sd_forward<11, 16>(A, stream);
+        case 12: return launch_sd_forward<12, 16>(A, stream);
+        case 13: return launch_sd_forward<13, 16>(A, stream);
+        case 14: return launch_sd_forward<14, 16>(A, stream);
+        case 15: return launch_sd_forward<15, 16>(A, stream);
+        case 16: return launch_sd_forward<16, 16>(A, stream);
+    }
+    return fail(TPR_E_UNSUPPORTED, "dof out of range");
+}
+
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
     if (A.B == 0) return TPR_E_OK;
     int variant = p->variant;
@@ -227,6 +264,50 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream_) {
     A.status = S.out(r->status, B);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (int rc = launch_solve(p, A, stream)) return rc;
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired, double atol,
+                                     const tpr_result *r, double *alpha, void *stream_) {
+    if (int rc = check_problem(p)) return rc;
+    if (!r || !r->K || !desired) return fail(TPR_E_BADARG, "result.K and desired are required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::BatchArgs A = stage_problem(p, S);
+    if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "TOPPRAsd needs an acceleration constraint with Interpolation");
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    const double *ddes = S.in(desired, B);
+    A.sd2 = S.out(r->sd2, B * (N + 1));
+    A.sd = S.out(r->sd, B * (N + 1));
+    A.u = S.out(r->u, B * N);
+    A.K = S.out(r->K, B * (N + 1) * 2);
+    A.status = S.out(r->status, B);
+    double *dalpha = S.out(alpha, B);
+    // workspace: fastest / slowest profiles and a status array when the caller wants none
+    double *ws = nullptr;
+    int32_t *wstatus = nullptr;
+    const size_t per = 2 * (N + 1) + 2 * N;
+    if (S.err == hipSuccess) S.err = hipMalloc(reinterpret_cast<void **>(&ws), B * per * sizeof(double) + 8);
+    if (S.err == hipSuccess && !A.status) {
+        S.err = hipMalloc(reinterpret_cast<void **>(&wstatus), B * sizeof(int32_t) + 4);
+        A.status = wstatus;
+    }
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    S.owned.push_back(ws);
+    if (wstatus) S.owned.push_back(wstatus);
+    if (A.B > 0) {
+        tpr_problem q = *p;
+        q.variant = 2;
+        if (int rc = launch_solve(&q, A, stream)) return rc;  // backward scan -> K, controllability
+        tpr::SdArgs F{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim, A.sd_start, A.K,
+                      A.status, ws, ws + B * (N + 1), ws + B * (2 * N + 1), ws + B * (3 * N + 2)};
+        if (int rc = dispatch_sd_forward(A.d, F, stream)) return rc;
+        tpr::SdBlendArgs G{A.B, A.N, A.flags, atol, A.grid, ddes, F.xf, F.uf, F.xl, F.ul, A.status,
+                           A.sd2, A.sd, A.u, dalpha, A.status};
+        hipLaunchKernelGGL(tpr::sd_blend_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, G);
+    }
+    if (p->flags & TPR_DEVICE_PTRS) HIP_TRY(hipStreamSynchronize(stream));  // the workspace is freed on return
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }

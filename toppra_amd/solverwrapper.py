@@ -127,6 +127,12 @@ class hipSeidelWrapper(SolverWrapper):
                                 np.array([sd_end], dtype=np.float64), self._interp, want_sd=True)
         return {k: v[0] for k, v in out.items()}
 
+    def parameterization_sd(self, sd_start, sd_end, desired_duration, atol=1e-5):
+        out = batch.solve_desired_duration_batch(*self._args(), desired_duration,
+                                                 np.array([sd_start], dtype=np.float64),
+                                                 np.array([sd_end], dtype=np.float64), atol)
+        return {k: v[0] for k, v in out.items()}
+
     # -- single-LP compatibility entry ---------------------------------------------------------
     def solve_stagewise_optim(self, i, H, g, x_min, x_max, x_next_min, x_next_max):
         assert 0 <= i <= self.N
