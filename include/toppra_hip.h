@@ -110,6 +110,16 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream);
 int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired, double atol,
                                      const tpr_result *r, double *alpha, void *stream);
 
+/* Robust TOPP-RA (BASELINE config 4) -- PARITY UNPINNED, see csrc/tpr_robust.hip.inc.  Replaces
+ * TOPPRA([JointVelocityConstraint, RobustLinearConstraint(JointAccelerationConstraint, ellipsoid)],
+ * ..., solver_wrapper="ecos"): compute_parameterization (+ compute_feasible_sets into X when X !=
+ * NULL) with the stage problems ecosWrapper.solve_stagewise_optim builds
+ * (solverwrapper/ecos_solverwrapper.py:90-207, constraint/conic_constraint.py:19-26) solved exactly
+ * instead of by ECOS's interior-point iteration.  ellipsoid = (ru, rx, rc) axes lengths.  The
+ * acceleration discretisation follows p->flags (TPR_ACC_INTERPOLATION or Collocation).             */
+int tpr_robust_solve_batch(const tpr_problem *p, const double *ellipsoid, const tpr_result *r, double *X,
+                           void *stream);
+
 /* Replaces ReachabilityAlgorithm.compute_controllable_sets(sdmin, sdmax)
  * (reachability_algorithm.py:166-238).  sdmin/sdmax [B]; K [B][N+1][2].                          */
 int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const double *sdmax,

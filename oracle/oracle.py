@@ -74,6 +74,9 @@ def lib():
         L.orc_solve_batch_sd.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp, dp,
                                          dp, dp, dp, C.c_double, C.c_int, dp, dp, dp, C.POINTER(C.c_int32), dp,
                                          C.c_int]
+        L.orc_robust_solve_batch.restype = C.c_int
+        L.orc_robust_solve_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, C.c_int, dp, dp,
+                                             dp, dp, dp, C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int32), C.c_int]
         for name in ("a", "b", "c", "low", "high"):
             f = getattr(L, "orc_wrapper_" + name)
             f.restype = dp
@@ -216,6 +219,29 @@ class Wrapper:
         st = lib().orc_compute_parameterization(self._h, sd_start, sd_end, _dp(sdd), _dp(sd),
                                                 _dp(xs), _dp(K))
         return st, sdd, sd, xs, K
+
+
+def robust_solve_batch(coef, breaks, grid, vlim, alim, ellipsoid, sd_start=None, sd_end=None,
+                       flags=DEFAULT_FLAGS, want_X=True, nthreads=1):
+    """Robust (conic) TOPP-RA, PARITY UNPINNED (see seidel_oracle.c): dict(sd2, u, K, X, status)."""
+    coef, breaks, grid = _f64(coef), _f64(breaks), _f64(grid)
+    B, _, nseg, d = coef.shape
+    N = grid.shape[-1] - 1
+    vlim = _f64(vlim) if vlim is not None else None
+    alim = _f64(alim)
+    ell = _f64(ellipsoid)
+    sd_start = _f64(sd_start) if sd_start is not None else None
+    sd_end = _f64(sd_end) if sd_end is not None else None
+    sd2, u, K = np.zeros((B, N + 1)), np.zeros((B, N)), np.zeros((B, N + 1, 2))
+    X = np.zeros((B, N + 1, 2)) if want_X else None
+    status = np.zeros(B, dtype=np.int32)
+    if vlim is None:
+        flags &= ~FLAG_VEL
+    lib().orc_robust_solve_batch(B, d, nseg, N, _dp(coef), _dp(breaks), int(breaks.ndim == 2), _dp(grid),
+                                 int(grid.ndim == 2), _dp(vlim), _dp(alim), _dp(ell), _dp(sd_start), _dp(sd_end),
+                                 flags, _dp(sd2), _dp(u), _dp(K), _dp(X), status.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 int(nthreads))
+    return {"sd2": sd2, "u": u, "K": K, "X": X, "status": status}
 
 
 def solve_batch_sd(coef, breaks, grid, vlim, alim, desired_duration, sd_start=None, sd_end=None, atol=1e-5,

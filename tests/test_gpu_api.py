@@ -159,5 +159,5 @@ def test_robust_constraint_params(gpu, example, scheme):
     assert_same(c, fx["robust%d_c" % scheme], "c"); assert_same(P, fx["robust%d_P" % scheme], "P")
     assert ub is None and xb is None
     assert rc.get_constraint_type() == ta.constraint.ConstraintType.CanonicalConic
-    with pytest.raises(ta.exceptions.ToppraError):  # no conic solver in this build (reference: needs ecos)
-        ta.algorithm.TOPPRA([pc_vel, rc], path, gridpoints=fx["n100_grid"])
+    with pytest.raises(AssertionError):  # as in the reference: seidel cannot take conic constraints
+        ta.algorithm.TOPPRA([pc_vel, rc], path, gridpoints=fx["n100_grid"], solver_wrapper="seidel")

@@ -1,0 +1,78 @@
+"""Robust (conic) TOPP-RA, BASELINE config 4 -- PARITY UNPINNED (the reference's solver for these
+stage problems is ECOS, unavailable; its own tests here are skipped or qualitative).  What can be
+checked: the HIP kernel against the CPU restatement of the same method (bit for bit), the zero
+ellipsoid against the seidel LP path, nestedness, worst-case constraint satisfaction, and the
+reference's qualitative test (tests/tests/retime/test_retime_wconic_constraints.py:30-48)."""
+import numpy as np
+import pytest
+
+import toppra_amd as ta
+from tests.helpers import assert_same
+from toppra_amd import batch
+
+pytestmark = pytest.mark.gpu
+ELL = [1e-3, 5e-2, 9e-3]  # examples/plot_robust_kinematics.py:26-28
+
+
+@pytest.mark.parametrize("B,d,N,interp", [(96, 7, 100, True), (64, 3, 40, False), (40, 6, 150, True)])
+def test_kernel_matches_oracle(gpu, oracle, B, d, N, interp):
+    data = batch.make_synthetic_batch(B, d, N, seed=d)
+    rng = np.random.default_rng(0)
+    sd1 = np.where(rng.random(B) < 0.3, 0.2 * rng.random(B), 0.0)
+    got = batch.robust_solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], ELL,
+                                   None, sd1, interp, want_X=True)
+    flags = oracle.FLAG_VEL | oracle.FLAG_ACC | (oracle.FLAG_INTERP if interp else 0)
+    ref = oracle.robust_solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], ELL,
+                                    None, sd1, flags=flags, nthreads=0)
+    assert np.array_equal(got["status"], ref["status"]) and (ref["status"] == 0).mean() > 0.9
+    for k in ("K", "X", "sd2", "u"):
+        assert_same(got[k], ref[k], k)
+
+
+def test_zero_ellipsoid_is_the_lp_path(gpu):
+    data = batch.make_synthetic_batch(128, 7, 100, seed=9)
+    rob = batch.robust_solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], [0, 0, 0])
+    lp = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    assert np.array_equal(rob["status"], lp["status"])
+    assert np.nanmax(np.abs(rob["K"][:, :, 1] - lp["K"][:, :, 1])) < 1e-9
+    assert np.nanmax(np.abs(rob["sd2"] - lp["sd2"])) < 1e-8
+    assert np.nanmax(np.abs(rob["u"] - lp["u"])) < 1e-5  # u is less well conditioned than sd^2
+
+
+def test_nested_and_worst_case_feasible(gpu):
+    data = batch.make_synthetic_batch(64, 7, 80, seed=10)
+    lp = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    rob = batch.robust_solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], ELL)
+    ok = (rob["status"] == 0) & (lp["status"] == 0)
+    assert ok.mean() > 0.9
+    assert np.all(rob["K"][ok][:, :, 1] <= lp["K"][ok][:, :, 1] + 1e-9)      # robust sets are nested
+    # the profile itself is lower almost everywhere (at discretised switch points the greedy forward
+    # step can overshoot the nominal valley by ~1e-4: 5 of 5184 gridpoints here)
+    assert np.mean(rob["sd2"][ok] <= lp["sd2"][ok] + 1e-7) > 0.99
+    assert np.all(rob["sd2"][ok] <= lp["sd2"][ok] + 1e-3)
+    assert np.any(rob["sd2"][ok] < lp["sd2"][ok] - 1e-6)
+    # every conic row holds at the solution: a u + b x + c + ||(ru u, rx x, rc)|| <= 0
+    par = batch.constraint_params_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    a, b, c = (par[k][ok][:, :-1, 2:] for k in ("a", "b", "c"))
+    u, x = rob["u"][ok][:, :, None], rob["sd2"][ok][:, :-1, None]
+    res = a * u + b * x + c + np.sqrt((ELL[0] * u) ** 2 + (ELL[1] * x) ** 2 + ELL[2] ** 2)
+    assert np.max(res) <= 1e-7, np.max(res)
+    assert np.all(np.abs(par["qs"][ok][:, :-1] * np.sqrt(x)) <= data["vlim"][ok][:, None, :, 1] * (1 + 1e-5))
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_reference_qualitative_test(gpu, seed):
+    """tests/tests/retime/test_retime_wconic_constraints.py:30-48 with this build's solver."""
+    np.random.seed(seed)
+    path = ta.SplineInterpolator(np.linspace(0, 1, 5), np.random.randn(5, 3))
+    lims = np.array([[-1, 1], [-1, 2], [-1, 4]], dtype=float)
+    vel_c = ta.constraint.JointVelocityConstraint(lims)
+    acc_c = ta.constraint.JointAccelerationConstraint(lims, 1)
+    ro_acc_c = ta.constraint.RobustLinearConstraint(acc_c, [1e-4, 1e-4, 5e-4], 1)
+    inst = ta.algorithm.TOPPRA([vel_c, ro_acc_c], path, solver_wrapper="ecos")
+    X = inst.compute_feasible_sets()
+    assert np.all(X >= 0) and not np.any(np.isnan(X))
+    K = inst.compute_controllable_sets(0, 0)
+    assert np.all(K >= 0) and not np.any(np.isnan(K))
+    traj = inst.compute_trajectory(0, 0)
+    assert traj is not None and 0 < traj.duration < 20

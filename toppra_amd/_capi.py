@@ -50,7 +50,7 @@ EXPORTS = (
     "tpr_controllable_sets_batch", "tpr_feasible_sets_batch", "tpr_constraint_params_batch",
     "tpr_solve_stagewise_batch", "tpr_lp1d_batch", "tpr_lp2d_batch", "tpr_solve_batch_timed",
     "tpr_spline_fit_batch", "tpr_const_accel_times_batch", "tpr_const_accel_eval_batch",
-    "tpr_solve_desired_duration_batch",
+    "tpr_solve_desired_duration_batch", "tpr_robust_solve_batch",
 )
 
 _lib = None
@@ -94,6 +94,8 @@ def load():
         L.tpr_solve_batch.argtypes = [P, R, V]
         L.tpr_solve_desired_duration_batch.restype = C.c_int
         L.tpr_solve_desired_duration_batch.argtypes = [P, V, C.c_double, R, V, V]
+        L.tpr_robust_solve_batch.restype = C.c_int
+        L.tpr_robust_solve_batch.argtypes = [P, V, R, V, V]
         L.tpr_solve_batch_timed.restype = C.c_int
         L.tpr_solve_batch_timed.argtypes = [P, R, V, C.c_int, C.POINTER(C.c_float)]
         L.tpr_controllable_sets_batch.restype = C.c_int

@@ -16,7 +16,7 @@ from . import batch as _batch
 from . import exceptions
 from . import interpolator as _interp
 from .constants import SMALL
-from .solverwrapper import hipSeidelWrapper
+from .solverwrapper import hipRobustWrapper, hipSeidelWrapper
 
 logger = logging.getLogger(__name__)
 
@@ -114,14 +114,19 @@ class ReachabilityAlgorithm(ParameterizationAlgorithm):
                  **kwargs):
         super(ReachabilityAlgorithm, self).__init__(constraint_list, path, gridpoints=gridpoints,
                                                     parametrizer=parametrizer, **kwargs)
-        for c in constraint_list:
-            if getattr(c.get_constraint_type(), "value", None) == 1:
-                raise exceptions.ToppraError("Solverwrapper not available.")  # conic needs ecos
+        has_conic = any(getattr(c.get_constraint_type(), "value", None) == 1 for c in constraint_list)
         if solver_wrapper is None:
             solver_wrapper = "hip"
-        assert solver_wrapper.lower() in self._SOLVERS, "Solver {:} not found".format(solver_wrapper)
-        self.solver_wrapper = hipSeidelWrapper(self.constraints, self.path, self.gridpoints,
-                                               solve_lp1d=True)
+        if has_conic:
+            # the reference needs ecos / cvxpy here (reachability_algorithm.py:78-84); this build
+            # solves the same stage problems exactly on the GPU -- parity unpinned, see DESIGN.md
+            assert solver_wrapper.lower() in ("hip", "ecos"), \
+                "Problem has conic constraints, solver {:} is not suitable".format(solver_wrapper)
+            self.solver_wrapper = hipRobustWrapper(self.constraints, self.path, self.gridpoints)
+        else:
+            assert solver_wrapper.lower() in self._SOLVERS, "Solver {:} not found".format(solver_wrapper)
+            self.solver_wrapper = hipSeidelWrapper(self.constraints, self.path, self.gridpoints,
+                                                   solve_lp1d=True)
 
     def compute_feasible_sets(self):
         """X[N+1, 2]: feasible squared velocities per gridpoint (NaN where infeasible)."""

@@ -16,7 +16,7 @@ from . import _capi
 __all__ = ["solve_batch", "controllable_sets_batch", "feasible_sets_batch",
            "constraint_params_batch", "make_synthetic_batch", "spline_coefficients",
            "spline_fit_batch", "solve_batch_timed", "const_accel_times_batch", "const_accel_eval_batch",
-           "solve_desired_duration_batch"]
+           "solve_desired_duration_batch", "robust_solve_batch"]
 
 
 def _stream_ptr(like):
@@ -87,6 +87,27 @@ def solve_desired_duration_batch(coef, breaks, grid, vlim, alim, desired_duratio
                          K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
     _capi.check(_capi.load().tpr_solve_desired_duration_batch(C.byref(p), _capi.ptr(desired), float(atol), C.byref(r),
                                                               _capi.ptr(out["alpha"]), _stream_ptr(coef)))
+    return out
+
+
+def robust_solve_batch(coef, breaks, grid, vlim, alim, ellipsoid, sd_start=None, sd_end=None, interpolation=True,
+                       want_X=False):
+    """Robust TOPP-RA for B trajectories (``RobustLinearConstraint`` on the acceleration limits with
+    perturbation ellipsoid ``(ru, rx, rc)``; BASELINE config 4).  PARITY UNPINNED: the reference solves
+    these second-order-cone stage problems with ECOS; this solves the same problems exactly (see
+    csrc/tpr_robust.hip.inc).  Returns dict(sd2, sd, u, K, status[, X])."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation)
+    B, N = p.B, p.N
+    ell = np.ascontiguousarray(np.asarray(ellipsoid, dtype=np.float64).reshape(3))  # always a host array
+    out = {"sd2": _empty(coef, (B, N + 1)), "sd": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)),
+           "K": _empty(coef, (B, N + 1, 2)), "status": _empty(coef, (B,), "i32")}
+    if want_X:
+        out["X"] = _empty(coef, (B, N + 1, 2))
+    r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out["sd"]), u=_capi.ptr(out["u"]),
+                         K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
+    _capi.check(_capi.load().tpr_robust_solve_batch(C.byref(p), ell.ctypes.data, C.byref(r), _capi.ptr(out.get("X")),
+                                                    _stream_ptr(coef)))
     return out
 
 

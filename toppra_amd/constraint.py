@@ -164,10 +164,9 @@ class RobustLinearConstraint(ConicConstraint):
     ``a u + b x + c + ||diag(ru, rx, rc) [u, x, 1]||_2 <= 0`` for every row of the base constraint.
 
     ``compute_constraint_params`` returns the reference's 6-tuple
-    ``(a, b, c, P, ubound, xbound)``; the rows come from the HIP library.  Solving the resulting
-    second-order-cone stage problems needs the reference's ECOS back-end, which this build does not
-    replace: constructing a TOPPRA instance with a conic constraint raises ``ToppraError`` exactly
-    as the reference does when ecos is not installed (reachability_algorithm.py:66-70).
+    ``(a, b, c, P, ubound, xbound)``; the rows come from the HIP library.  The second-order-cone
+    stage problems (ECOS in the reference) are solved exactly on the GPU by
+    ``solverwrapper.hipRobustWrapper`` -- parity with ECOS is unpinned, see DESIGN.md.
     """
 
     def __init__(self, cnst, ellipsoid_axes_lengths, discretization_scheme=DiscretizationType.Collocation):

@@ -15,6 +15,7 @@
 #include "tpr_group.hip.inc"
 #include "tpr_spline.hip.inc"
 #include "tpr_param.hip.inc"
+#include "tpr_robust.hip.inc"
 
 namespace {
 
@@ -308,6 +309,31 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
         hipLaunchKernelGGL(tpr::sd_blend_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, G);
     }
     if (p->flags & TPR_DEVICE_PTRS) HIP_TRY(hipStreamSynchronize(stream));  // the workspace is freed on return
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_robust_solve_batch(const tpr_problem *p, const double *ellipsoid, const tpr_result *r, double *X,
+                           void *stream_) {
+    if (int rc = check_problem(p)) return rc;
+    if (!r || !r->K || !ellipsoid) return fail(TPR_E_BADARG, "result.K and ellipsoid are required");
+    if (!(p->flags & TPR_HAS_ACCELERATION)) return fail(TPR_E_BADARG, "the robust path needs an acceleration constraint");
+    if (ellipsoid[0] < 0 || ellipsoid[1] < 0 || ellipsoid[2] < 0) return fail(TPR_E_BADARG, "ellipsoid axes must be non-negative");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::RobustArgs P{};
+    P.A = stage_problem(p, S);
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    P.A.sd2 = S.out(r->sd2, B * (N + 1));
+    P.A.sd = S.out(r->sd, B * (N + 1));
+    P.A.u = S.out(r->u, B * N);
+    P.A.K = S.out(r->K, B * (N + 1) * 2);
+    P.A.status = S.out(r->status, B);
+    P.X = S.out(X, B * (N + 1) * 2);
+    P.ru = ellipsoid[0]; P.rx = ellipsoid[1]; P.rc = ellipsoid[2];
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (P.A.B > 0)
+        hipLaunchKernelGGL(tpr::robust_solve_kernel, dim3((P.A.B + 63) / 64), dim3(64), 0, stream, P);
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }

@@ -146,3 +146,61 @@ class hipSeidelWrapper(SolverWrapper):
             C.byref(p), _capi.ptr(stage), _capi.ptr(g), _capi.ptr(xb), _capi.ptr(self._active),
             self._solve_lp1d, _capi.ptr(out), None))
         return out[0]
+
+
+class hipRobustWrapper(SolverWrapper):
+    """Wrapper for [JointVelocityConstraint (optional), RobustLinearConstraint(JointAccelerationConstraint)]
+    problems -- the role ``ecosWrapper`` plays in the reference (ecos_solverwrapper.py:14-207).
+
+    PARITY UNPINNED: the stage problems are the ones the reference builds for ECOS, solved exactly
+    on the GPU (csrc/tpr_robust.hip.inc) instead of by ECOS's interior-point iteration."""
+
+    def __init__(self, constraint_list, path, path_discretization):
+        self.constraints = constraint_list
+        self.path = path
+        self.path_discretization = np.array(path_discretization, dtype=np.float64)
+        self.N = len(self.path_discretization) - 1
+        self.deltas = self.path_discretization[1:] - self.path_discretization[:-1]
+        self.nV = 2
+        coef, breaks = spline_tables(path)
+        self._coef, self._breaks = coef[None], breaks
+        self.dof = coef.shape[2]
+        self._vlim = self._alim = self._ell = None
+        self._interp = True
+        for c in constraint_list:
+            ctype = getattr(c.get_constraint_type(), "value", None)
+            if ctype == 1 and hasattr(c, "base_constraint") and hasattr(c.base_constraint, "alim"):
+                if self._alim is not None:
+                    raise NotImplementedError("more than one robust constraint")
+                self._alim = np.ascontiguousarray(c.base_constraint.alim, dtype=np.float64)[None]
+                self._ell = np.asarray(c.ellipsoid_axes_lengths, dtype=np.float64).reshape(3)
+                self._interp = getattr(c.get_discretization_type(), "value", 0) == 1
+            elif ctype == 0 and hasattr(c, "vlim") and not hasattr(c, "vlim_func"):
+                self._vlim = np.ascontiguousarray(c.vlim, dtype=np.float64)[None]
+            else:
+                raise NotImplementedError("%s is outside the robust HIP path" % type(c).__name__)
+            if c.get_dof() != self.dof:
+                raise ValueError("Wrong dimension: constraint dof ({:d}) not equal to path dof ({:d})".format(
+                    c.get_dof(), self.dof))
+        if self._alim is None:
+            raise NotImplementedError("the robust path needs a RobustLinearConstraint over JointAccelerationConstraint")
+
+    def _solve(self, sd_start, sd_end, want_X=False):
+        out = batch.robust_solve_batch(self._coef, self._breaks, self.path_discretization, self._vlim, self._alim,
+                                       self._ell, np.array([sd_start], dtype=np.float64),
+                                       np.array([sd_end], dtype=np.float64), self._interp, want_X=want_X)
+        return {k: v[0] for k, v in out.items()}
+
+    def parameterization(self, sd_start, sd_end):
+        return self._solve(sd_start, sd_end)
+
+    def controllable_sets(self, sdmin, sdmax):
+        if sdmin != sdmax:
+            raise NotImplementedError("robust controllable sets are implemented for sdmin == sdmax")
+        return self._solve(sdmin, sdmax)["K"]
+
+    def feasible_sets(self):
+        return self._solve(0.0, 0.0, want_X=True)["X"]
+
+    def solve_stagewise_optim(self, i, H, g, x_min, x_max, x_next_min, x_next_max):
+        raise NotImplementedError("the robust wrapper works at the pass level only")
