@@ -176,6 +176,35 @@ def example_fixture():
     print("example_kinematics_seed9: N auto =", len(out["auto_grid"]) - 1, "status", out["n100_status"], out["auto_status"])
 
 
+def hard_fixture():
+    """Asymmetric limits (incl. strictly positive lower velocity limits), 10 waypoints on random
+    non-uniform knots, a non-uniform grid, one joint that does not move, non-zero end velocities."""
+    rng = np.random.default_rng(2024)
+    B, d, N, m = 32, 6, 90, 10
+    knots = np.concatenate([[0.0], np.sort(rng.random(m - 2)) * 2.5 + 0.1, [2.8]])
+    grid = np.concatenate([[knots[0]], np.sort(rng.random(N - 1)) * (knots[-1] - knots[0]) + knots[0], [knots[-1]]])
+    recs = {k: [] for k in ("coef", "K", "sd", "u", "status", "X", "vlim", "alim")}
+    sd1 = np.where(np.arange(B) % 3 == 0, 0.05, 0.0)
+    for b in range(B):
+        way = rng.standard_normal((m, d))
+        if b % 4 == 0:
+            way[:, 2] = way[0, 2]                       # joint 2 stands still
+        vl = np.stack([-(2 + 20 * rng.random(d)), 5 + 20 * rng.random(d)], 1)
+        al = np.stack([-(3 + 10 * rng.random(d)), 8 + 4 * rng.random(d)], 1)
+        if b % 5 == 1:
+            way = np.cumsum(np.abs(way), axis=0)          # monotone joints ...
+            vl[:, 0] = 0.01 * rng.random(d)               # ... allow a positive lower velocity limit
+        rec, inst, path, cons = solve_one(knots, way, grid, vl, al, 0.0, sd1[b], 1, want_feasible=True)
+        for k in ("coef", "K", "sd", "u", "status", "X"):
+            recs[k].append(rec[k])
+        recs["vlim"].append(vl); recs["alim"].append(al)
+    np.savez_compressed(os.path.join(OUT, "batch_d6_N90_hard.npz"), coef=np.stack(recs["coef"]), breaks=knots, grid=grid,
+                        vlim=np.stack(recs["vlim"]), alim=np.stack(recs["alim"]), sd_start=np.zeros(B), sd_end=sd1,
+                        K=np.stack(recs["K"]), sd=np.stack(recs["sd"]), u=np.stack(recs["u"]), X=np.stack(recs["X"]),
+                        status=np.array(recs["status"], dtype=np.int32), interpolation=np.array(1))
+    print("batch_d6_N90_hard status counts", np.bincount(recs["status"], minlength=3))
+
+
 def sd_fixture():
     """TOPPRAsd (desired_duration_algorithm.py) on random problems: unachievably short, in-range and
     unachievably long desired durations, some with boundary velocities."""
@@ -274,6 +303,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     example_fixture()
     cpp_fixture()
+    hard_fixture()
     sd_fixture()
     lp_fixture()
     batch_fixture("batch_d7_N200", 32, 7, 200, seed=20240924)
