@@ -13,6 +13,7 @@
 #include "tpr_device.hpp"
 #include "tpr_lane.hip.inc"
 #include "tpr_group.hip.inc"
+#include "tpr_cert.hip.inc"
 #include "tpr_spline.hip.inc"
 #include "tpr_param.hip.inc"
 #include "tpr_robust.hip.inc"
@@ -185,11 +186,46 @@ int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
     return fail(TPR_E_UNSUPPORTED, "dof out of range");
 }
 
+// The certified lane kernel (family 3) serves the same constraint set up to 8 dof when sd2, u and
+// status are requested; the strict and relaxed modes stay with family 2.
+bool cert_supported(const tpr::BatchArgs &A) {
+    return group_supported(A) && A.d <= 8 && !(A.flags & (TPR_STRICT_SEIDEL | TPR_RELAXED_LOWER)) && A.sd2 && A.u &&
+           A.status && A.N >= 1;
+}
+
+template <int D>
+int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
+    constexpr int BS = 64;
+    tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
+                     A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
+    const dim3 grid((A.B + BS - 1) / BS), block(BS);
+    const size_t grid_bytes = (size_t)(A.N + 1) * sizeof(double);
+    const bool grid_lds = !(A.flags & TPR_GRID_PER_TRAJ) && grid_bytes <= 16 * 1024;
+    const size_t lds = grid_lds ? grid_bytes : 0;
+    if (A.sd) {
+        if (grid_lds) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, true, true>), grid, block, lds, stream, G);
+        else hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, true, false>), grid, block, lds, stream, G);
+    } else {
+        if (grid_lds) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, false, true>), grid, block, lds, stream, G);
+        else hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, false, false>), grid, block, lds, stream, G);
+    }
+    return TPR_E_OK;
+}
+
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
     if (A.B == 0) return TPR_E_OK;
     int variant = p->variant;
     if (variant == 0) variant = group_supported(A) ? 2 : 1;
     switch (variant) {
+        case 3: {
+            if (!cert_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs acceleration+interpolation, d <= 8, default mode");
+            switch (A.d) {
+                case 3: return launch_cert<3>(A, stream);
+                case 6: return launch_cert<6>(A, stream);
+                case 7: return launch_cert<7>(A, stream);
+            }
+            return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
+        }
         case 2: {
             if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 2 needs acceleration+interpolation");
             switch (A.d) {
