@@ -49,11 +49,13 @@ def test_full_size_properties(gpu, oracle, B, d, N):
     assert np.array_equal(out["status"][idx], ref["status"])
     for k in ("K", "sd2", "u"):
         assert np.array_equal(out[k][idx], ref[k], equal_nan=True), k
-    # the two kernel families agree bit for bit on a 4096 slice
+    # the three kernel families agree bit for bit on a 4096 slice (the default is family 3 here)
     sl = slice(0, 4096)
-    v1 = batch.solve_batch(data["coef"][sl], data["breaks"], data["grid"], data["vlim"][sl], data["alim"][sl], variant=1)
-    for k in ("K", "sd2", "u", "status"):
-        assert np.array_equal(out[k][sl], v1[k], equal_nan=True), k
+    for variant in (1, 2):
+        v = batch.solve_batch(data["coef"][sl], data["breaks"], data["grid"], data["vlim"][sl], data["alim"][sl],
+                              variant=variant)
+        for k in ("K", "sd2", "u", "status"):
+            assert np.array_equal(out[k][sl], v[k], equal_nan=True), (variant, k)
 
 
 @pytest.mark.parametrize("B,d,N,seed", [(65536, 7, 200, 20240924), (32768, 6, 500, 3), (16384, 3, 100, 5),
@@ -69,8 +71,44 @@ def test_lower_bound_shortcut_is_exact(gpu, B, d, N, seed):
     scale = 10.0 ** rng.uniform(-6, 0, size=(B, 1, 1, 1))
     for coef, s0, s1 in ((data["coef"], sd0, sd1), (data["coef"] * scale, None, None)):
         args = (coef, data["breaks"], data["grid"], data["vlim"], data["alim"], s0, s1)
-        fast = batch.solve_batch(*args)
         full = batch.solve_batch(*args, strict=True)
         assert len(np.unique(full["status"])) >= (1 if s0 is not None else 2)
+        for variant in (2, 3):  # rows-across-lanes with shortcuts; certified lane kernel (the default for d <= 8)
+            fast = batch.solve_batch(*args, variant=variant)
+            for k in ("K", "sd2", "u", "status"):
+                assert np.array_equal(fast[k], full[k], equal_nan=True), (variant, k)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_certified_lane_kernel_all_dofs(gpu, oracle, d):
+    """Kernel family 3 for every dof it serves, odd batch sizes (idle lanes), per-trajectory grids and
+    breakpoints, no velocity constraint, sd requested, non-zero boundary velocities: identical bits to
+    the full iteration of family 2 and to the oracle."""
+    B, N = 1000 + d, 60 + 7 * d
+    data = batch.make_synthetic_batch(B, d, N, seed=40 + d, n_waypoints=4 + d % 3)
+    rng = np.random.default_rng(d)
+    sd0 = np.where(rng.random(B) < 0.5, 0.2 * rng.random(B), 0.0)
+    sd1 = np.where(rng.random(B) < 0.5, 0.2 * rng.random(B), 0.0)
+    grid_b = np.sort(np.concatenate([np.zeros((B, 1)), rng.random((B, N - 1)), np.ones((B, 1))], axis=1), axis=1)
+    grid_b[:, 1:-1] = 0.5 * grid_b[:, 1:-1] + 0.5 * data["grid"][None, 1:-1]  # keep the steps away from zero
+    breaks_b = np.repeat(data["breaks"][None], B, axis=0)
+    cases = [
+        (data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], sd0, sd1),
+        (data["coef"], breaks_b, grid_b, data["vlim"], data["alim"], None, None),
+        (data["coef"], data["breaks"], data["grid"], None, data["alim"], None, sd1),
+    ]
+    for ci, args in enumerate(cases):
+        full = batch.solve_batch(*args, strict=True, want_sd=True)
+        got = batch.solve_batch(*args, variant=3, want_sd=True)
+        auto = batch.solve_batch(*args)
+        for k in ("K", "sd2", "sd", "u", "status"):
+            assert np.array_equal(got[k], full[k], equal_nan=True), (ci, k)
         for k in ("K", "sd2", "u", "status"):
-            assert np.array_equal(fast[k], full[k], equal_nan=True), k
+            assert np.array_equal(auto[k], full[k], equal_nan=True), (ci, k)
+    idx = np.arange(0, B, 7)
+    ref = oracle.solve_batch(data["coef"][idx], data["breaks"], data["grid"], data["vlim"][idx], data["alim"][idx],
+                             sd0[idx], sd1[idx], nthreads=0)
+    got = batch.solve_batch(*cases[0], variant=3)
+    assert np.array_equal(got["status"][idx], ref["status"])
+    for k in ("K", "sd2", "u"):
+        assert np.array_equal(got[k][idx], ref[k], equal_nan=True), k

@@ -202,26 +202,33 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
     const size_t grid_bytes = (size_t)(A.N + 1) * sizeof(double);
     const bool grid_lds = !(A.flags & TPR_GRID_PER_TRAJ) && grid_bytes <= 16 * 1024;
     const size_t lds = grid_lds ? grid_bytes : 0;
-    if (A.sd) {
-        if (grid_lds) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, true, true>), grid, block, lds, stream, G);
-        else hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, true, false>), grid, block, lds, stream, G);
-    } else {
-        if (grid_lds) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, false, true>), grid, block, lds, stream, G);
-        else hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, false, false>), grid, block, lds, stream, G);
-    }
+    // One 64-lane block per wave; ~33 KB of LDS per block leaves one wave per SIMD, which the kernel
+    // is written for (the whole register file, stalls covered by unrolled independent row work).
+#define TPR_LAUNCH_CERT(SD, GL) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, SD, GL>), grid, block, lds, stream, G)
+    if (A.sd) { if (grid_lds) TPR_LAUNCH_CERT(true, true); else TPR_LAUNCH_CERT(true, false); }
+    else { if (grid_lds) TPR_LAUNCH_CERT(false, true); else TPR_LAUNCH_CERT(false, false); }
+#undef TPR_LAUNCH_CERT
     return TPR_E_OK;
 }
 
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
     if (A.B == 0) return TPR_E_OK;
     int variant = p->variant;
-    if (variant == 0) variant = group_supported(A) ? 2 : 1;
+    if (variant == 0) variant = cert_supported(A) ? 3 : (group_supported(A) ? 2 : 1);
     switch (variant) {
         case 3: {
-            if (!cert_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs acceleration+interpolation, d <= 8, default mode");
+            if (!cert_supported(A))
+                return fail(TPR_E_UNSUPPORTED, "variant 3 needs acceleration+interpolation, d <= 8, sd2/u/status outputs, default mode");
             switch (A.d) {
+#ifndef TPR_CERT_DEV  // development builds instantiate 7 dof only
+                case 1: return launch_cert<1>(A, stream);
+                case 2: return launch_cert<2>(A, stream);
                 case 3: return launch_cert<3>(A, stream);
+                case 4: return launch_cert<4>(A, stream);
+                case 5: return launch_cert<5>(A, stream);
                 case 6: return launch_cert<6>(A, stream);
+                case 8: return launch_cert<8>(A, stream);
+#endif
                 case 7: return launch_cert<7>(A, stream);
             }
             return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
