@@ -6,7 +6,7 @@ B, d, N = 65536, 7, 200
 data = batch.make_synthetic_batch(B, d, N)
 out = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], variant=3)
 t = out["u"][:, :12]
-names = ["bwd loop overhead+K store", "bwd eval+box", "norms", "upper walk", "batch setup (both LPs) + results", "lower cert(+walk)", "lower fallback",
+names = ["bwd loop overhead+K store", "bwd eval+box(+norms)", "batch: publish+ballot", "lane-level checks (upper+lower)", "batch: build rows", "batch results+state update", "batch: pick lanes",
          "fwd overhead(prefetch, update, stores)", "fwd eval", "fwd lp1d", "batch: walk (predict_upper_lp)", "batch: seidel"]
 m = t.mean(0)
 print("cycles per wave (mean over lanes), share:")
