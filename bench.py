@@ -46,12 +46,12 @@ def pmc_traffic(B, d, N, kernel_ms):
             pmc = json.load(fh)
     except (OSError, ValueError):
         return None
-    if int(pmc["counters"].get("_Grid_Size", 0)) != B * 8 or (d, N) != (7, 200) or "hbm_bytes_per_launch" not in pmc:
+    if int(pmc["counters"].get("_Grid_Size", 0)) not in (B, B * 8) or (d, N) != (7, 200) or "hbm_bytes_per_launch" not in pmc:
         return None
     return {"bytes_per_launch": pmc["hbm_bytes_per_launch"],
             "bytes_per_launch_fetch_x2": pmc["hbm_bytes_per_launch_fetch_x2"],
             "gbps": pmc["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9,
-            "valu_busy": pmc.get("valu_busy"), "avg_active_lanes": pmc.get("avg_active_lanes"),
+            "kernel": pmc.get("kernel"), "valu_busy": pmc.get("valu_busy"), "avg_active_lanes": pmc.get("avg_active_lanes"),
             "source": "profiles/r01_pmc.json (rocprofv3 --pmc, separate passes)"}
 
 
@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=5)
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the strict / relaxed secondary measurements (used under rocprofv3 so that the "
+                    help="skip the secondary (full iteration, family 2) measurements (used under rocprofv3 so that the "
                          "kernel statistics cover the headline mode only)")
     args = ap.parse_args()
 
@@ -126,9 +126,8 @@ def main():
     if world > 1 and rank == 0:
         gather_list = [torch.empty((B, N + 1), dtype=torch.float64, device=dev) for _ in range(world)]
 
-    def step(relaxed=False):
-        out = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"],
-                             variant=args.variant, relaxed=relaxed)
+    def step():
+        out = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], variant=args.variant)
         if world > 1:
             dist.gather(out["sd2"], gather_list, dst=0)
         return out
@@ -153,29 +152,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # secondary: the opt-in relaxed mode (skips provably-zero lower-bound LPs), same protocol
-    secondary_steps = 0 if args.no_secondary else args.steps
-    relaxed_out = step(relaxed=True) if secondary_steps else out
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(secondary_steps):
-        relaxed_out = step(relaxed=True)
-    fence()
-    elapsed_relaxed = max(time.perf_counter() - t0, 1e-9)
-    if world > 1:
-        t = torch.tensor([elapsed_relaxed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_relaxed = float(t.item())
-    dev_sd2 = float(torch.nan_to_num(out["sd2"] - relaxed_out["sd2"]).abs().max().item())
-    dev_K = float(torch.nan_to_num(out["K"] - relaxed_out["K"]).abs().max().item())
-
     # dominant kernel: average launch duration with HIP events on the launch stream
     kernel_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], out,
                                      reps=args.kernel_reps, variant=args.variant)
-    strict_ms = None
+    # secondary (single-GPU kernel times, not the headline): the reference's full Seidel iteration for
+    # every LP (TPR_STRICT_SEIDEL, kernel family 2) and family 2 with its certified shortcuts; the
+    # default path must return the same bits as the full iteration
+    strict_ms = family2_ms = same_bits = None
     if not args.no_secondary:
-        strict_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], out,
-                                         reps=max(2, args.kernel_reps // 2), variant=args.variant, strict=True)
+        reps = max(2, args.kernel_reps // 2)
+        full = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], strict=True)
+        same_bits = all(bool(torch.equal(torch.nan_to_num(out[k], nan=-7.0), torch.nan_to_num(full[k], nan=-7.0)))
+                        for k in ("sd2", "u", "K")) and bool(torch.equal(out["status"], full["status"]))
+        strict_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], full,
+                                         reps=reps, strict=True)
+        family2_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], full,
+                                          reps=reps, variant=2)
     ok_frac = float((out["status"] == 0).double().mean().item())
 
     if rank == 0:
@@ -205,18 +197,18 @@ def main():
             },
             "waypoint_lps_per_s": 3 * N * traj_per_s,
             "secondary_measured": not args.no_secondary,
-            "strict_seidel": {
-                "note": "TPR_STRICT_SEIDEL: every lower-bound LP through the full Seidel iteration instead of the "
-                        "certified shortcut (identical bits; single-GPU kernel time only)",
+            "full_iteration": {
+                "note": "TPR_STRICT_SEIDEL: every stage LP through the reference's full Seidel iteration (kernel "
+                        "family 2) instead of the certified answers; single-GPU kernel time only",
                 "kernel_ms": strict_ms, "value_per_gpu": (B / strict_ms * 1e3) if strict_ms else None,
                 "unit": "trajectories/s",
+                "default_path_returns_identical_bits": same_bits,
             },
-            "relaxed_mode": {
-                "note": "opt-in TPR_RELAXED_LOWER: backward lower-bound LPs whose answer is provably 0 are "
-                        "skipped (~2N instead of 3N LPs per trajectory); NOT the headline value",
-                "value": world * B * secondary_steps / elapsed_relaxed, "unit": "trajectories/s",
-                "ms_per_step": elapsed_relaxed / max(secondary_steps, 1) * 1e3,
-                "max_abs_dev_sd2_vs_exact": dev_sd2, "max_abs_dev_K_vs_exact": dev_K,
+            "family2_rows_across_lanes": {
+                "note": "kernel family 2 (8 lanes per trajectory) with its certified shortcuts; serves d > 8 and the "
+                        "strict mode; single-GPU kernel time only",
+                "kernel_ms": family2_ms, "value_per_gpu": (B / family2_ms * 1e3) if family2_ms else None,
+                "unit": "trajectories/s",
             },
             "ok_fraction": ok_frac,
             "roofline": {
@@ -229,7 +221,8 @@ def main():
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_trajectory": bytes_per_traj,
                 "pmc": pmc,
-                "note": "fused path is fp64-VALU bound (VALU busy ~91%), not HBM bound: DESIGN.md section 3.3",
+                "note": "the fused path is bound by fp64 VALU issue and, at one wave per SIMD, by its own dependency "
+                        "latencies -- not by HBM: DESIGN.md section 3.3",
             },
         }
         if not args.no_cpu_baseline:

@@ -73,7 +73,7 @@ def test_lower_bound_shortcut_is_exact(gpu, B, d, N, seed):
         args = (coef, data["breaks"], data["grid"], data["vlim"], data["alim"], s0, s1)
         full = batch.solve_batch(*args, strict=True)
         assert len(np.unique(full["status"])) >= (1 if s0 is not None else 2)
-        for variant in (2, 3):  # rows-across-lanes with shortcuts; certified lane kernel (the default for d <= 8)
+        for variant in (2, 3):  # rows-across-lanes with shortcuts; certified lane kernel (default for large batches, d <= 8)
             fast = batch.solve_batch(*args, variant=variant)
             for k in ("K", "sd2", "u", "status"):
                 assert np.array_equal(fast[k], full[k], equal_nan=True), (variant, k)

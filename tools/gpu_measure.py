@@ -39,6 +39,10 @@ if __name__ == "__main__":
     res = {
         "headline_65536x7x200": device_rate(65536, 7, 200),
         "c2_4096x7x200": device_rate(4096, 7, 200),
+        "c2_4096x7x200_family3": device_rate(4096, 7, 200, variant=3),
+        "b32768x7x200_family2": device_rate(32768, 7, 200, variant=2),
+        "b32768x7x200_family3": device_rate(32768, 7, 200, variant=3),
+        "headline_family2": device_rate(65536, 7, 200, variant=2),
         "c3_65536x6x500": device_rate(65536, 6, 500, reps=2),
         "headline_lane_kernel": device_rate(65536, 7, 200, variant=1, reps=2),
         "host_buffers_65536x7x200": host_rate(65536, 7, 200),

@@ -214,7 +214,10 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
     if (A.B == 0) return TPR_E_OK;
     int variant = p->variant;
-    if (variant == 0) variant = cert_supported(A) ? 3 : (group_supported(A) ? 2 : 1);
+    // auto: family 3 finishes up to 65536 trajectories (one wave per SIMD) in one fixed-latency round,
+    // which beats family 2's throughput from about half that batch upward; smaller batches spread
+    // better over the chip with family 2's 8 lanes per trajectory
+    if (variant == 0) variant = (cert_supported(A) && A.B >= 32768) ? 3 : (group_supported(A) ? 2 : 1);
     switch (variant) {
         case 3: {
             if (!cert_supported(A))
