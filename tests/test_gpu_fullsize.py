@@ -112,3 +112,17 @@ def test_certified_lane_kernel_all_dofs(gpu, oracle, d):
     assert np.array_equal(got["status"][idx], ref["status"])
     for k in ("K", "sd2", "u"):
         assert np.array_equal(got[k][idx], ref[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("B,d,N", [(40000, 7, 48), (700, 5, 60), (600, 12, 30)])
+def test_controllable_sets_on_fast_kernels(gpu, oracle, B, d, N):
+    """compute_controllable_sets(sdmin, sdmax) with sdmin != sdmax runs the backward scan of the fast
+    kernels (family 3 for the large batch, family 2 for the small / 12-dof ones): oracle parity on a sample."""
+    data = batch.make_synthetic_batch(B, d, N, seed=77 + d)
+    rng = np.random.default_rng(B)
+    sdmin = np.where(rng.random(B) < 0.5, 0.0, 0.2 * rng.random(B))
+    sdmax = sdmin + np.where(rng.random(B) < 0.5, 0.0, 0.5 * rng.random(B))
+    K = batch.controllable_sets_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], sdmin, sdmax)
+    for b in rng.choice(B, size=120, replace=False):
+        w = oracle.Wrapper(data["coef"][b], data["breaks"], data["grid"], data["vlim"][b], data["alim"][b])
+        assert np.array_equal(K[b], w.compute_controllable_sets(sdmin[b], sdmax[b]), equal_nan=True), b

@@ -131,7 +131,7 @@ int launch_group(const tpr::BatchArgs &A, hipStream_t stream) {
         if (group_lds_bytes<D, L>(A.nseg, t, table_in_lds) <= kMaxDynamicLds) { threads = t; break; }
     while (threads > 64 && (long long)A.B * L / threads < 4 * 256) threads /= 2;
     tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
-                     A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
+                     A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status, A.sd_end_hi, A.backward_only};
     const int groups = threads / L;
     size_t lds = group_lds_bytes<D, L>(A.nseg, threads, table_in_lds);
     if (const char *pad = std::getenv("TPR_LDS_PAD")) lds += (size_t)std::atoi(pad);  // occupancy experiments
@@ -189,15 +189,15 @@ int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
 // The certified lane kernel (family 3) serves the same constraint set up to 8 dof when sd2, u and
 // status are requested; the strict and relaxed modes stay with family 2.
 bool cert_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && A.d <= 8 && !(A.flags & (TPR_STRICT_SEIDEL | TPR_RELAXED_LOWER)) && A.sd2 && A.u &&
-           A.status && A.N >= 1;
+    return group_supported(A) && A.d <= 8 && !(A.flags & (TPR_STRICT_SEIDEL | TPR_RELAXED_LOWER)) && A.N >= 1 &&
+           (A.backward_only || (A.sd2 && A.u && A.status));
 }
 
 template <int D>
 int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
     constexpr int BS = 64;
     tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
-                     A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
+                     A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status, A.sd_end_hi, A.backward_only};
     const dim3 grid((A.B + BS - 1) / BS), block(BS);
     const size_t grid_bytes = (size_t)(A.N + 1) * sizeof(double);
     const bool grid_lds = !(A.flags & TPR_GRID_PER_TRAJ) && grid_bytes <= 16 * 1024;
@@ -421,9 +421,17 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
     const double *dmin = S.in(sdmin, B), *dmax = S.in(sdmax, B);
     A.K = S.out(K, B * (N + 1) * 2);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    if (A.B > 0)
-        hipLaunchKernelGGL(tpr::lane_controllable_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A,
-                           dmin, dmax);
+    if (A.B > 0) {
+        if (group_supported(A) && A.N >= 1) {  // the backward scan of the fast kernels
+            A.sd_end = dmin;
+            A.sd_end_hi = dmax;
+            A.backward_only = 1;
+            if (int rc = launch_solve(p, A, stream)) return rc;
+        } else {
+            hipLaunchKernelGGL(tpr::lane_controllable_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A,
+                               dmin, dmax);
+        }
+    }
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
