@@ -48,12 +48,14 @@ extern "C" {
  * Results stay within ~1e-13 of the reference (bound asserted in the tests: 1e-8) instead of being
  * bit-identical.  Honoured by the rows-across-lanes kernels; ignored elsewhere.                    */
 #define TPR_RELAXED_LOWER 64
-/* Force every stage LP through the full Seidel iteration.  By default the rows-across-lanes kernels
- * answer the backward lower-bound LP from a verified certificate (the optimal vertex is "x on its box
- * bound, u on the tightest row", checked with margins 1e3..1e4 above the solver's tolerances) and
- * evaluate the reference's own pivot formulas for that vertex; marginal cases fall back to the full
- * iteration.  Both give the same bits (cross-checked on ~1e8 stage LPs, tests/test_gpu_fullsize.py);
- * this flag exists for A/B testing and for callers who want the iteration itself replicated.        */
+/* Force every stage LP through the full Seidel iteration (served by the rows-across-lanes kernels).
+ * By default the fast kernels answer a backward LP from a verified optimal vertex -- found as "x on its
+ * box bound, u on the tightest row" (lower bound) or as the previous stage's active pair, if need be
+ * after a short simplex walk (upper bound), and checked with margins 1e3..1e4 above the solver's
+ * tolerances -- by evaluating the reference's own last-pivot formulas for it; what does not verify
+ * runs the full iteration.  Both give the same bits (cross-checked on ~1e8 stage LPs,
+ * tests/test_gpu_fullsize.py); this flag exists for A/B testing and for callers who want the
+ * iteration itself replicated.                                                                     */
 #define TPR_STRICT_SEIDEL 128
 
 /* per-trajectory status == ParameterizationReturnCode (algorithm/algorithm.py:49-62) */
@@ -70,7 +72,8 @@ extern "C" {
 typedef struct tpr_problem {
     int32_t B, d, nseg, N;
     int32_t flags;
-    int32_t variant; /* kernel selection: 0 = auto, 1 = lane-per-trajectory, 2 = rows-across-lanes */
+    int32_t variant; /* kernel selection: 0 = auto, 1 = generic lane-per-trajectory, 2 = rows-across-lanes,
+                        3 = lane-per-trajectory certificates (d <= 8; sd2, u, status required) */
     const double *coef;
     const double *breaks;
     const double *grid;
