@@ -222,7 +222,7 @@ def main():
                 "algorithmic_bytes_per_trajectory": bytes_per_traj,
                 "pmc": pmc,
                 "note": "the fused path is bound by fp64 VALU issue and, at one wave per SIMD, by its own dependency "
-                        "latencies -- not by HBM: DESIGN.md section 3.3",
+                        "latencies -- not by HBM: DESIGN.md section 3.5",
             },
         }
         if not args.no_cpu_baseline:

@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""Where the default kernel (family 3) spends its cycles: per-phase cycle counters of every wave,
+accumulated in-kernel with s_memtime by a -DTPR_CERT_TIMING build and returned through `u`.
+
+    python -m toppra_amd.build -DTPR_CERT_TIMING -DTPR_CERT_DEV --out=build_dbg/libtoppra_tim.so   (build container)
+    TOPPRA_HIP_LIB=build_dbg/libtoppra_tim.so python tools/gpu_cert_phases.py                     (GPU box)
+"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from toppra_amd import batch
+B, d, N = 65536, 7, 200
+data = batch.make_synthetic_batch(B, d, N)
+out = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], variant=3)
+t = out["u"][:, :12]
+names = ["backward: loop, K staging", "backward: spline + velocity box (+ row norms)", "batches: publish scalars, queue",
+         "lane-level certificates (upper + lower LP)", "batches: rebuild rows across lanes", "batches: results, warm-start update",
+         "batches: pick queue entries", "forward: prefetch, update, output staging", "forward: spline evaluation",
+         "forward: 1-variable LP (30 divisions)", "batches: simplex walk (predict_upper_lp)", "batches: full Seidel iteration"]
+m = t.mean(0)
+print("cycles per wave (mean over lanes) for B=%d d=%d N=%d:" % (B, d, N))
+for n, v in sorted(zip(names, m), key=lambda p: -p[1]):
+    print("  %-50s %12.0f  %5.1f%%   per stage %8.0f" % (n, v, 100 * v / m.sum(), v / N))
+print("  total %.0f cycles = %.3f ms at 2.4 GHz" % (m.sum(), m.sum() / 2.4e6))

@@ -40,15 +40,23 @@ def stale():
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in deps())
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
+def build(force=False, verbose=False, defines=(), out=None):
+    """Build the library.  ``defines`` / ``out`` produce an instrumented copy next to the product one
+    (e.g. defines=("TPR_CERT_TIMING", "TPR_CERT_DEV"), used by tools/gpu_cert_phases.py via
+    TOPPRA_HIP_LIB); the product library is always built without defines."""
+    target = os.path.abspath(out) if out else LIB
+    if not defines and not out and not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    cmd = [hipcc()] + FLAGS + ["-D" + d for d in defines] + ["-o", target] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    args = sys.argv[1:]
+    defs = [a[2:] for a in args if a.startswith("-D")]
+    outs = [a.split("=", 1)[1] for a in args if a.startswith("--out=")]
+    print(build(force="--force" in args, verbose=True, defines=defs, out=outs[0] if outs else None))
