@@ -126,3 +126,24 @@ def test_controllable_sets_on_fast_kernels(gpu, oracle, B, d, N):
     for b in rng.choice(B, size=120, replace=False):
         w = oracle.Wrapper(data["coef"][b], data["breaks"], data["grid"], data["vlim"][b], data["alim"][b])
         assert np.array_equal(K[b], w.compute_controllable_sets(sdmin[b], sdmax[b]), equal_nan=True), b
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (3, 7), (63, 8), (65, 9), (130, 15), (64, 16), (100, 17), (70, 2100)])
+def test_certified_lane_kernel_edge_shapes(gpu, oracle, B, N):
+    """Family 3 at the edges of its launch geometry: single trajectories and partly filled waves, stage
+    counts around the 8-stage output staging, a grid too long for its LDS copy (N = 2100)."""
+    d = 4
+    data = batch.make_synthetic_batch(B, d, N, seed=1000 + N)
+    rng = np.random.default_rng(N)
+    sd0, sd1 = 0.1 * rng.random(B), 0.1 * rng.random(B)
+    args = (data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], sd0, sd1)
+    got = batch.solve_batch(*args, variant=3, want_sd=True)
+    full = batch.solve_batch(*args, strict=True, want_sd=True)
+    for k in ("K", "sd2", "sd", "u", "status"):
+        assert np.array_equal(got[k], full[k], equal_nan=True), k
+    n = min(B, 8)
+    ref = oracle.solve_batch(data["coef"][:n], data["breaks"], data["grid"], data["vlim"][:n], data["alim"][:n],
+                             sd0[:n], sd1[:n], nthreads=0)
+    for k in ("K", "sd2", "u"):
+        assert np.array_equal(got[k][:n], ref[k], equal_nan=True), k
+    assert np.array_equal(got["status"][:n], ref["status"])
