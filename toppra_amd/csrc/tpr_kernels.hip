@@ -47,13 +47,13 @@ struct Staging {
 
     Staging(bool dev, hipStream_t s) : device_ptrs(dev), stream(s) {}
     ~Staging() {
-        for (void *p : owned) (void)hipFree(p);
+        for (void *p : owned) (void)hipFreeAsync(p, stream);  // stream-ordered pool: no device sync, memory is reused
     }
     template <class T>
     const T *in(const T *p, size_t count) {
         if (!p || device_ptrs || count == 0) return p;
         void *d = nullptr;
-        if (err == hipSuccess) err = hipMalloc(&d, count * sizeof(T));
+        if (err == hipSuccess) err = hipMallocAsync(&d, count * sizeof(T), stream);
         if (err != hipSuccess) return nullptr;
         owned.push_back(d);
         err = hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, stream);
@@ -63,7 +63,7 @@ struct Staging {
     T *out(T *p, size_t count, bool copy_in = false) {
         if (!p || device_ptrs || count == 0) return p;
         void *d = nullptr;
-        if (err == hipSuccess) err = hipMalloc(&d, count * sizeof(T));
+        if (err == hipSuccess) err = hipMallocAsync(&d, count * sizeof(T), stream);
         if (err != hipSuccess) return nullptr;
         owned.push_back(d);
         if (copy_in) err = hipMemcpyAsync(d, p, count * sizeof(T), hipMemcpyHostToDevice, stream);
