@@ -159,7 +159,7 @@ def main():
     # every LP (TPR_STRICT_SEIDEL, kernel family 2) and family 2 with its certified shortcuts; the
     # default path must return the same bits as the full iteration
     strict_ms = family2_ms = same_bits = None
-    if not args.no_secondary:
+    if not args.no_secondary and world == 1:
         reps = max(2, args.kernel_reps // 2)
         full = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], strict=True)
         same_bits = all(bool(torch.equal(torch.nan_to_num(out[k], nan=-7.0), torch.nan_to_num(full[k], nan=-7.0)))
@@ -196,7 +196,7 @@ def main():
                 "kernel_variant": args.variant,
             },
             "waypoint_lps_per_s": 3 * N * traj_per_s,
-            "secondary_measured": not args.no_secondary,
+            "secondary_measured": (not args.no_secondary) and world == 1,
             "full_iteration": {
                 "note": "TPR_STRICT_SEIDEL: every stage LP through the reference's full Seidel iteration (kernel "
                         "family 2) instead of the certified answers; single-GPU kernel time only",
@@ -225,7 +225,7 @@ def main():
                         "latencies -- not by HBM: DESIGN.md section 3.5",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline(data)
         print(json.dumps(line))
     if world > 1:
