@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ELL = [1e-3, 5e-2, 9e-3]  # examples/plot_robust_kinematics.py:26-28
 
 
-@pytest.mark.parametrize("B,d,N,interp", [(96, 7, 100, True), (64, 3, 40, False), (40, 6, 150, True)])
+@pytest.mark.parametrize("B,d,N,interp", [(96, 7, 100, True), (64, 3, 40, False), (40, 6, 150, True), (300, 8, 60, True), (33, 1, 30, True)])
 def test_kernel_matches_oracle(gpu, oracle, B, d, N, interp):
     data = batch.make_synthetic_batch(B, d, N, seed=d)
     rng = np.random.default_rng(0)
@@ -27,6 +27,12 @@ def test_kernel_matches_oracle(gpu, oracle, B, d, N, interp):
     assert np.array_equal(got["status"], ref["status"]) and (ref["status"] == 0).mean() > 0.9
     for k in ("K", "X", "sd2", "u"):
         assert_same(got[k], ref[k], k)
+    # without feasible sets the Interpolation case runs the rows-across-lanes kernel: same bits
+    fast = batch.robust_solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], ELL,
+                                    None, sd1, interp)
+    assert np.array_equal(fast["status"], ref["status"])
+    for k in ("K", "sd2", "u"):
+        assert_same(fast[k], ref[k], k)
 
 
 def test_zero_ellipsoid_is_the_lp_path(gpu):

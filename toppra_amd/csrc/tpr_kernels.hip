@@ -211,6 +211,38 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
     return TPR_E_OK;
 }
 
+template <int D>
+int launch_group_robust(const tpr::RobustArgs &P, hipStream_t stream) {
+    constexpr int L = 8;
+    const tpr::BatchArgs &A = P.A;
+    if (group_lds_bytes<D, L>(A.nseg, 64, true) > kMaxDynamicLds) {  // very long spline tables: lane kernel
+        hipLaunchKernelGGL(tpr::robust_solve_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, P);
+        return TPR_E_OK;
+    }
+    int threads = 64;
+    for (int t = 256; t > 64; t /= 2)
+        if (group_lds_bytes<D, L>(A.nseg, t, true) <= kMaxDynamicLds) { threads = t; break; }
+    while (threads > 64 && (long long)A.B * L / threads < 4 * 256) threads /= 2;
+    const int groups = threads / L;
+    const size_t lds = group_lds_bytes<D, L>(A.nseg, threads, true);
+    hipLaunchKernelGGL((tpr::group_robust_kernel<D, L>), dim3((A.B + groups - 1) / groups), dim3(threads), lds, stream, P);
+    return TPR_E_OK;
+}
+
+int dispatch_group_robust(const tpr::RobustArgs &P, hipStream_t stream) {
+    switch (P.A.d) {
+        case 1: return launch_group_robust<1>(P, stream);
+        case 2: return launch_group_robust<2>(P, stream);
+        case 3: return launch_group_robust<3>(P, stream);
+        case 4: return launch_group_robust<4>(P, stream);
+        case 5: return launch_group_robust<5>(P, stream);
+        case 6: return launch_group_robust<6>(P, stream);
+        case 7: return launch_group_robust<7>(P, stream);
+        case 8: return launch_group_robust<8>(P, stream);
+    }
+    return fail(TPR_E_UNSUPPORTED, "dof out of range");
+}
+
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
     if (A.B == 0) return TPR_E_OK;
     int variant = p->variant;
@@ -383,8 +415,13 @@ int tpr_robust_solve_batch(const tpr_problem *p, const double *ellipsoid, const 
     P.X = S.out(X, B * (N + 1) * 2);
     P.ru = ellipsoid[0]; P.rx = ellipsoid[1]; P.rc = ellipsoid[2];
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    if (P.A.B > 0)
-        hipLaunchKernelGGL(tpr::robust_solve_kernel, dim3((P.A.B + 63) / 64), dim3(64), 0, stream, P);
+    if (P.A.B > 0) {
+        if (!P.X && group_supported(P.A) && P.A.d <= 8) {  // rows across lanes; feasible sets / Collocation: lane kernel
+            if (int rc = dispatch_group_robust(P, stream)) return rc;
+        } else {
+            hipLaunchKernelGGL(tpr::robust_solve_kernel, dim3((P.A.B + 63) / 64), dim3(64), 0, stream, P);
+        }
+    }
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
