@@ -147,3 +147,14 @@ def test_certified_lane_kernel_edge_shapes(gpu, oracle, B, N):
     for k in ("K", "sd2", "u"):
         assert np.array_equal(got[k][:n], ref[k], equal_nan=True), k
     assert np.array_equal(got["status"][:n], ref["status"])
+
+
+@pytest.mark.parametrize("B,d,N", [(300, 7, 50), (200, 12, 40), (129, 2, 33)])
+def test_feasible_sets_on_fast_kernel(gpu, oracle, B, d, N):
+    """compute_feasible_sets runs the rows-across-lanes kernel (incl. the final gridpoint's duplicated
+    interpolation block and the warm-start state carried from stage to stage): oracle parity."""
+    data = batch.make_synthetic_batch(B, d, N, seed=5 + d)
+    X = batch.feasible_sets_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    for b in range(0, B, 7):
+        w = oracle.Wrapper(data["coef"][b], data["breaks"], data["grid"], data["vlim"][b], data["alim"][b])
+        assert np.array_equal(X[b], w.compute_feasible_sets(), equal_nan=True), b

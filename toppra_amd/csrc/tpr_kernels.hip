@@ -211,6 +211,45 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
     return TPR_E_OK;
 }
 
+template <int D, int L>
+int launch_group_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream) {
+    const bool table_in_lds = group_lds_bytes<D, L>(A.nseg, 64, true) <= kMaxDynamicLds;
+    int threads = 64;
+    for (int t = 256; t > 64; t /= 2)
+        if (group_lds_bytes<D, L>(A.nseg, t, table_in_lds) <= kMaxDynamicLds) { threads = t; break; }
+    while (threads > 64 && (long long)A.B * L / threads < 4 * 256) threads /= 2;
+    tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
+                     A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
+    const int groups = threads / L;
+    const size_t lds = group_lds_bytes<D, L>(A.nseg, threads, table_in_lds);
+    const dim3 grid((A.B + groups - 1) / groups), block(threads);
+    if (table_in_lds) hipLaunchKernelGGL((tpr::group_feasible_kernel<D, L, true>), grid, block, lds, stream, G, X);
+    else hipLaunchKernelGGL((tpr::group_feasible_kernel<D, L, false>), grid, block, lds, stream, G, X);
+    return TPR_E_OK;
+}
+
+int dispatch_group_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream) {
+    switch (A.d) {
+        case 1: return launch_group_feasible<1, 8>(A, X, stream);
+        case 2: return launch_group_feasible<2, 8>(A, X, stream);
+        case 3: return launch_group_feasible<3, 8>(A, X, stream);
+        case 4: return launch_group_feasible<4, 8>(A, X, stream);
+        case 5: return launch_group_feasible<5, 8>(A, X, stream);
+        case 6: return launch_group_feasible<6, 8>(A, X, stream);
+        case 7: return launch_group_feasible<7, 8>(A, X, stream);
+        case 8: return launch_group_feasible<8, 8>(A, X, stream);
+        case 9: return launch_group_feasible<9, 16>(A, X, stream);
+        case 10: return launch_group_feasible<10, 16>(A, X, stream);
+        case 11: return launch_group_feasible<11, 16>(A, X, stream);
+        case 12: return launch_group_feasible<12, 16>(A, X, stream);
+        case 13: return launch_group_feasible<13, 16>(A, X, stream);
+        case 14: return launch_group_feasible<14, 16>(A, X, stream);
+        case 15: return launch_group_feasible<15, 16>(A, X, stream);
+        case 16: return launch_group_feasible<16, 16>(A, X, stream);
+    }
+    return fail(TPR_E_UNSUPPORTED, "dof out of range");
+}
+
 template <int D>
 int launch_group_robust(const tpr::RobustArgs &P, hipStream_t stream) {
     constexpr int L = 8;
@@ -486,8 +525,13 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
     tpr::BatchArgs A = stage_problem(p, S);
     double *dX = S.out(X, (size_t)p->B * (p->N + 1) * 2);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    if (A.B > 0)
-        hipLaunchKernelGGL(tpr::lane_feasible_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dX);
+    if (A.B > 0) {
+        if (group_supported(A)) {
+            if (int rc = dispatch_group_feasible(A, dX, stream)) return rc;
+        } else {
+            hipLaunchKernelGGL(tpr::lane_feasible_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dX);
+        }
+    }
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
