@@ -411,18 +411,16 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
     double *ws = nullptr;
     int32_t *wstatus = nullptr;
     const size_t per = 2 * (N + 1) + 2 * N;
-    if (S.err == hipSuccess) S.err = hipMalloc(reinterpret_cast<void **>(&ws), B * per * sizeof(double) + 8);
+    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * per * sizeof(double) + 8, stream);
     if (S.err == hipSuccess && !A.status) {
-        S.err = hipMalloc(reinterpret_cast<void **>(&wstatus), B * sizeof(int32_t) + 4);
+        S.err = hipMallocAsync(reinterpret_cast<void **>(&wstatus), B * sizeof(int32_t) + 4, stream);
         A.status = wstatus;
     }
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     S.owned.push_back(ws);
     if (wstatus) S.owned.push_back(wstatus);
     if (A.B > 0) {
-        tpr_problem q = *p;
-        q.variant = 2;
-        if (int rc = launch_solve(&q, A, stream)) return rc;  // backward scan -> K, controllability
+        if (int rc = launch_solve(p, A, stream)) return rc;  // time-optimal solve -> K, controllability
         tpr::SdArgs F{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim, A.sd_start, A.K,
                       A.status, ws, ws + B * (N + 1), ws + B * (2 * N + 1), ws + B * (3 * N + 2)};
         if (int rc = dispatch_sd_forward(A.d, F, stream)) return rc;
@@ -430,7 +428,6 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
                            A.sd2, A.sd, A.u, dalpha, A.status};
         hipLaunchKernelGGL(tpr::sd_blend_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, G);
     }
-    if (p->flags & TPR_DEVICE_PTRS) HIP_TRY(hipStreamSynchronize(stream));  // the workspace is freed on return
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
