@@ -122,17 +122,20 @@ def main():
     dv = {k: torch.from_numpy(np.ascontiguousarray(data[k])).to(dev)
           for k in ("coef", "breaks", "grid", "vlim", "alim")}
 
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [torch.empty((B, N + 1), dtype=torch.float64, device=dev) for _ in range(world)]
+    # N > 1: the only communication is the gather of sd^2 to rank 0 (RCCL); it is issued asynchronously so
+    # that step k's gather rides the xGMI links while step k+1 is being solved (toppra_amd/distributed.py)
+    from toppra_amd.distributed import PipelinedGather
+    gatherer = PipelinedGather(B, N + 1, torch.float64, dev) if world > 1 else None
 
     def step():
         out = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], variant=args.variant)
-        if world > 1:
-            dist.gather(out["sd2"], gather_list, dst=0)
+        if gatherer is not None:
+            gatherer.submit(out["sd2"])
         return out
 
     def fence():
+        if gatherer is not None:
+            gatherer.finish()  # the last step's gather is inside the timed region
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -192,7 +195,7 @@ def main():
                 "workload": "batch=%d per GPU, %d-DoF random cubic splines (5 waypoints), N=%d gridpoints, "
                             "JointVelocity+JointAcceleration(Interpolation), seidel path, fp64" % (B, d, N),
                 "global_batch": world * B, "dof": d, "gridpoints": N,
-                "parallelism": "shard%d+rccl_gather(sd2)" % world if world > 1 else "single",
+                "parallelism": "shard%d+rccl_gather(sd2, overlapped with the next step)" % world if world > 1 else "single",
                 "kernel_variant": args.variant,
             },
             "waypoint_lps_per_s": 3 * N * traj_per_s,

@@ -69,3 +69,39 @@ def test_shard_bounds_partition():
             assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _pipeline_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from toppra_amd import distributed
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pg = distributed.PipelinedGather(4, 3, torch.float64, "cpu")
+    seen = []
+    for step in range(5):  # step k's gather overlaps step k+1's "solve"
+        local = torch.full((4, 3), float(10 * step + rank), dtype=torch.float64)
+        pg.submit(local)
+        if rank == 0 and step > 0:
+            pass  # buffers of step k-1 may already be overwritten; only the last step is inspected
+    bufs = pg.finish()
+    if rank == 0:
+        assert len(bufs) == world
+        for r in range(world):
+            assert torch.equal(bufs[r], torch.full((4, 3), float(40 + r), dtype=torch.float64))
+        open(os.path.join(tmp, "ok"), "w").write("1")
+    else:
+        assert bufs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_world2(tmp_path):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok"))

@@ -68,3 +68,45 @@ def solve_sharded(arrays, solve_fn, to_tensor, dst=0, group=None):
     local = solve_fn(shard)
     full = gather_rows(to_tensor(local["sd2"]), arrays["coef"].shape[0], dst=dst, group=group)
     return local, full
+
+
+class PipelinedGather:
+    """Gather of equal row shards to `dst`, overlapped with the next step's compute.
+
+    ``submit(local)`` issues the gather of ``local [rows, cols]`` asynchronously -- RCCL runs it on its
+    own stream, ordered after the kernels that produced ``local`` -- and returns at once, so the next
+    solve is launched while the previous result is still on the xGMI links.  At most one gather is in
+    flight: the previous one is waited for (a stream-level wait with RCCL) before the receive buffers
+    are reused.  ``finish()`` waits for the last one and returns the receive buffers on `dst`."""
+
+    def __init__(self, rows, cols, dtype, device, dst=0, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self._dist, self.dst, self.group = dist, dst, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.bufs = None
+        if self.world > 1 and self.rank == dst:
+            self.bufs = [torch.empty((rows, cols), dtype=dtype, device=device) for _ in range(self.world)]
+        self._pending = None  # (work, tensor kept alive while the collective reads it)
+
+    def submit(self, local):
+        if self.world == 1:
+            self._pending = (None, local)
+            return
+        self._wait()
+        work = self._dist.gather(local, self.bufs, dst=self.dst, group=self.group, async_op=True)
+        self._pending = (work, local)
+
+    def _wait(self):
+        if self._pending is not None and self._pending[0] is not None:
+            self._pending[0].wait()
+        self._pending = None
+
+    def finish(self):
+        last = self._pending[1] if self._pending is not None else None
+        self._wait()
+        if self.world == 1:
+            return [last] if last is not None else None
+        return self.bufs
