@@ -423,7 +423,11 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
     S.owned.push_back(ws);
     if (wstatus) S.owned.push_back(wstatus);
     if (A.B > 0) {
-        if (int rc = launch_solve(p, A, stream)) return rc;  // time-optimal solve -> K, controllability
+        {  // backward scan -> K and the controllability verdict (the time-optimal forward scan is not needed)
+            tpr::BatchArgs Ab = A;
+            Ab.backward_only = 1;
+            if (int rc = launch_solve(p, Ab, stream)) return rc;
+        }
         tpr::SdArgs F{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim, A.sd_start, A.K,
                       A.status, ws, ws + B * (N + 1), ws + B * (2 * N + 1), ws + B * (3 * N + 2)};
         if (int rc = dispatch_sd_forward(A.d, F, stream)) return rc;
