@@ -35,6 +35,32 @@ def host_rate(B, d, N, reps=3):
     return {"B": B, "d": d, "N": N, "host_ms": dt * 1e3, "traj_per_s_pcie_inclusive": B / dt}
 
 
+def other_entries(B=65536, d=7, N=200):
+    """TOPPRAsd, stand-alone controllable / feasible sets, robust config 4 (device tensors in and out)."""
+    data = tb.make_synthetic_batch(B, d, N)
+    dev = torch.device("cuda", 0)
+    dv = [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]
+    zero = torch.zeros(B, dtype=torch.float64, device=dev)
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    res = {
+        "toppra_sd_65536x7x200_ms": timed(lambda: tb.solve_desired_duration_batch(*dv, 3.0)),
+        "controllable_sets_65536x7x200_ms": timed(lambda: tb.controllable_sets_batch(*dv, zero, zero)),
+        "feasible_sets_65536x7x200_ms": timed(lambda: tb.feasible_sets_batch(*dv)),
+    }
+    data4 = tb.make_synthetic_batch(16384, 7, 100)
+    dv4 = [torch.from_numpy(np.ascontiguousarray(data4[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]
+    res["robust_config4_16384x7x100_ms"] = timed(lambda: tb.robust_solve_batch(*dv4, [1e-3, 5e-2, 9e-3]))
+    return res
+
+
 if __name__ == "__main__":
     res = {
         "headline_65536x7x200": device_rate(65536, 7, 200),
@@ -47,5 +73,6 @@ if __name__ == "__main__":
         "headline_lane_kernel": device_rate(65536, 7, 200, variant=1, reps=2),
         "host_buffers_65536x7x200": host_rate(65536, 7, 200),
         "b262144x7x200": device_rate(262144, 7, 200, reps=2),
+        "other_entries": other_entries(),
     }
     print(json.dumps(res, indent=1))
