@@ -1,6 +1,7 @@
 """HIP path against outputs of the REAL reference (tests/golden): bit-exact K / sd / u / X /
 status, through the C-ABI, for both kernel families.  Stated tolerance of the north star is
-1e-8 on sd^2; exact equality is asserted because the kernels replicate the reference's arithmetic."""
+1e-8 on sd^2; exact equality is asserted because the kernels replicate the reference's arithmetic.
+Fixtures cover d = 1 .. 16 (tools/make_golden.py)."""
 import ctypes as C
 
 import numpy as np
@@ -14,7 +15,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _variants(d, interp, has_vel=True):
-    return [1, 2] if (interp and d <= 8) else [1]
+    # 1 generic lane kernel; 2 rows across lanes (8 lanes up to 8 dof, 16 above); 3 certified lane kernel
+    if not interp:
+        return [1]
+    return [1, 2, 3] if d <= 8 else [1, 2]
 
 
 @pytest.mark.parametrize("name", batch_fixtures())
@@ -41,7 +45,7 @@ def test_example_kinematics(gpu, tag):
     fx = golden("example_kinematics_seed9")
     grid = fx[tag + "_grid"]
     d = fx["coef"].shape[3]
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         got = batch.solve_batch(fx["coef"], fx["breaks"], grid, fx["vlim"], fx["alim"], want_sd=True,
                                 variant=variant)
         assert got["status"][0] == 0

@@ -313,3 +313,9 @@ if __name__ == "__main__":
     batch_fixture("batch_d4_N80_acc_only", 16, 4, 80, seed=6, with_vel=False)
     batch_fixture("batch_d7_N120_tight", 24, 7, 120, seed=8, vscale=0.02, ascale=0.02, feasible=True)
     batch_fixture("batch_d5_N100_tiny_motion", 48, 5, 100, seed=9, wayscale=(-5.5, -0.5))
+    # the dof range of the kernel families: 1, 2 (family 3 / 8 lanes), 9, 14, 16 (16 lanes per trajectory)
+    batch_fixture("batch_d1_N40", 12, 1, 40, seed=11, feasible=True)
+    batch_fixture("batch_d2_N50_boundary", 12, 2, 50, seed=12, sd_mode="random")
+    batch_fixture("batch_d9_N60", 8, 9, 60, seed=13, feasible=True)
+    batch_fixture("batch_d14_N40_boundary", 6, 14, 40, seed=14, sd_mode="random")
+    batch_fixture("batch_d16_N30", 4, 16, 30, seed=15)
