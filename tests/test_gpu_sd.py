@@ -9,8 +9,9 @@ from toppra_amd import batch
 pytestmark = pytest.mark.gpu
 
 
-def test_sd_fixture(gpu):
-    fx = golden("sd_batch_d5_N80")
+@pytest.mark.parametrize("name", ["sd_batch_d5_N80", "sd_batch_d10_N50"])
+def test_sd_fixture(gpu, name):
+    fx = golden(name)
     out = batch.solve_desired_duration_batch(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"],
                                              fx["desired"], fx["sd_start"], fx["sd_end"])
     assert np.array_equal(out["status"], fx["status"]) and set(fx["status"]) == {0, 1}

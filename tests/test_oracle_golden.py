@@ -81,9 +81,10 @@ def test_random_lps(oracle):
             assert val == fx["optval1"][t] and var == fx["optvar1"][t] and ac == fx["active1"][t]
 
 
-def test_sd_fixture_oracle(oracle):
+@pytest.mark.parametrize("name", ["sd_batch_d5_N80", "sd_batch_d10_N50"])
+def test_sd_fixture_oracle(oracle, name):
     """TOPPRAsd restatement (oracle) vs the reference's outputs."""
-    fx = golden("sd_batch_d5_N80")
+    fx = golden(name)
     out = oracle.solve_batch_sd(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"], fx["desired"],
                                 fx["sd_start"], fx["sd_end"])
     assert np.array_equal(out["status"], fx["status"])

@@ -205,11 +205,10 @@ def hard_fixture():
     print("batch_d6_N90_hard status counts", np.bincount(recs["status"], minlength=3))
 
 
-def sd_fixture():
+def sd_fixture(name="sd_batch_d5_N80", B=24, d=5, N=80, seed=31):
     """TOPPRAsd (desired_duration_algorithm.py) on random problems: unachievably short, in-range and
     unachievably long desired durations, some with boundary velocities."""
-    rng = np.random.default_rng(31)
-    B, d, N = 24, 5, 80
+    rng = np.random.default_rng(seed)
     way = rng.standard_normal((B, 5, d))
     vmax = 10 + 20 * rng.random((B, d)); amax = 10 + 2 * rng.random((B, d))
     knots = np.linspace(0, 1, 5); grid = np.linspace(0, 1, N + 1)
@@ -231,11 +230,11 @@ def sd_fixture():
             sd = np.full(N + 1, np.nan); sdd = np.full(N, np.nan)
         recs["coef"].append(np.asarray(path.cspl.c)); recs["K"].append(K); recs["sd"].append(sd)
         recs["u"].append(sdd); recs["status"].append(st); recs["desired"].append(desired)
-    np.savez_compressed(os.path.join(OUT, "sd_batch_d5_N80.npz"), coef=np.stack(recs["coef"]), breaks=knots, grid=grid,
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), coef=np.stack(recs["coef"]), breaks=knots, grid=grid,
                         vlim=np.stack([-vmax, vmax], -1), alim=np.stack([-amax, amax], -1), sd_start=sd0, sd_end=sd1,
                         desired=np.array(recs["desired"]), K=np.stack(recs["K"]), sd=np.stack(recs["sd"]),
                         u=np.stack(recs["u"]), status=np.array(recs["status"], dtype=np.int32))
-    print("sd_batch_d5_N80 status counts", np.bincount(recs["status"], minlength=3))
+    print(name, "status counts", np.bincount(recs["status"], minlength=3))
 
 
 def cpp_fixture():
@@ -305,6 +304,7 @@ if __name__ == "__main__":
     cpp_fixture()
     hard_fixture()
     sd_fixture()
+    sd_fixture("sd_batch_d10_N50", B=12, d=10, N=50, seed=32)
     lp_fixture()
     batch_fixture("batch_d7_N200", 32, 7, 200, seed=20240924)
     batch_fixture("batch_d6_N500", 8, 6, 500, seed=20240925)
