@@ -1,0 +1,13 @@
+#!/bin/bash
+# Copy the judged summaries of the last tools/gpu_full.sh visit from gpurun_out/ into profiles/ (round tag $1).
+set -eu
+R=${1:-r01}
+cp gpurun_out/bench.log profiles/${R}_bench_n1.json
+cp gpurun_out/pmc.json profiles/${R}_pmc.json
+cp gpurun_out/pmc_summary.txt profiles/${R}_rocprofv3_pmc_summary.txt
+cp gpurun_out/prof_stats/run_kernel_stats.csv profiles/${R}_rocprofv3_kernel_stats.csv
+cp gpurun_out/measure.json profiles/${R}_secondary_measurements.json
+cp gpurun_out/stress.log profiles/${R}_shortcut_vs_full_seidel_stress.log
+[ -f gpurun_out/hitrate.log ] && cp gpurun_out/hitrate.log profiles/${R}_shortcut_hit_rate.log
+[ -f gpurun_out/phases.log ] && cp gpurun_out/phases.log profiles/${R}_family3_cycle_breakdown.log
+ls -la profiles | tail -12

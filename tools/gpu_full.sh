@@ -1,11 +1,26 @@
 #!/bin/bash
-# Full GPU visit: tests, smoke, bench (+cpu baseline), rocprof stats + PMC, secondary measurements.
+# Full GPU visit: tests, smoke, bench (+cpu baseline), secondary measurements, rocprof stats + PMC (then a
+# second bench run that picks the fresh PMC numbers up), stress, and -- when the instrumented builds of
+# `python -m toppra_amd.build -DTPR_CERT_TIMING -DTPR_CERT_DEV --out=build_dbg/libtoppra_tim.so` and
+# `... -DTPR_DEBUG_PREDICT -DTPR_CERT_DEV --out=build_dbg/libtoppra_dbg.so` are present -- the in-kernel
+# cycle breakdown and the certificate hit rates.  Everything lands under gpurun_out/; copy what should be
+# judged into profiles/ (tools/collect_profiles.sh).
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -5 | tee gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
-timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
 timeout 600 python tools/gpu_measure.py 2>/dev/null > gpurun_out/measure.json; tail -5 gpurun_out/measure.json
 rm -rf gpurun_out/prof_*
 bash tools/gpu_profile.sh "--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --kernel-reps 2" all > gpurun_out/profile.log 2>&1
 tail -3 gpurun_out/profile.log
+python tools/pmc_summary.py gpurun_out solve_kernel > gpurun_out/pmc_summary.txt
+python tools/pmc_summary.py gpurun_out solve_kernel --json > gpurun_out/pmc.json
+cp gpurun_out/pmc.json profiles/r01_pmc.json   # bench.py reads roofline.traffic from here
+timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
+timeout 900 python tools/gpu_shortcut_stress.py > gpurun_out/stress.log 2>&1; grep total gpurun_out/stress.log
+if [ -f build_dbg/libtoppra_tim.so ]; then
+  TOPPRA_HIP_LIB=build_dbg/libtoppra_tim.so timeout 300 python tools/gpu_cert_phases.py > gpurun_out/phases.log 2>&1; tail -3 gpurun_out/phases.log
+fi
+if [ -f build_dbg/libtoppra_dbg.so ]; then
+  TOPPRA_HIP_LIB=build_dbg/libtoppra_dbg.so TPR_DEV_BUILD=1 timeout 300 python tools/gpu_shortcut_hitrate.py > gpurun_out/hitrate.log 2>&1; tail -3 gpurun_out/hitrate.log
+fi
