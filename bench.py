@@ -38,9 +38,13 @@ def algorithmic_bytes(d, N, nseg):
 
 def pmc_traffic(B, d, N, kernel_ms):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc.json, produced by tools/gpu_profile.sh + tools/pmc_summary.py --json).
+    (profiles/rNN_pmc.json, produced by tools/gpu_profile.sh + tools/pmc_summary.py --json).
     Only valid for the shape it was collected on; returns None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))  # the latest round's passes
+    if not cands:
+        return None
+    path = cands[-1]
     try:
         with open(path) as fh:
             pmc = json.load(fh)
@@ -52,7 +56,7 @@ def pmc_traffic(B, d, N, kernel_ms):
             "bytes_per_launch_fetch_x2": pmc["hbm_bytes_per_launch_fetch_x2"],
             "gbps": pmc["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9,
             "kernel": pmc.get("kernel"), "valu_busy": pmc.get("valu_busy"), "avg_active_lanes": pmc.get("avg_active_lanes"),
-            "source": "profiles/r01_pmc.json (rocprofv3 --pmc, separate passes)"}
+            "source": "profiles/%s (rocprofv3 --pmc, separate passes)" % os.path.basename(path)}
 
 
 def cpu_baseline(data, target_seconds=12.0):

@@ -15,7 +15,7 @@ bash tools/gpu_profile.sh "--steps 3 --warmup 1 --no-cpu-baseline --no-secondary
 tail -3 gpurun_out/profile.log
 python tools/pmc_summary.py gpurun_out solve_kernel > gpurun_out/pmc_summary.txt
 python tools/pmc_summary.py gpurun_out solve_kernel --json > gpurun_out/pmc.json
-cp gpurun_out/pmc.json profiles/r01_pmc.json   # bench.py reads roofline.traffic from here
+cp gpurun_out/pmc.json profiles/${ROUND:-r01}_pmc.json   # bench.py reads roofline.traffic from the latest profiles/r*_pmc.json
 timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
 timeout 900 python tools/gpu_shortcut_stress.py > gpurun_out/stress.log 2>&1; grep total gpurun_out/stress.log
 if [ -f build_dbg/libtoppra_tim.so ]; then
