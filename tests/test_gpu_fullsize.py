@@ -158,3 +158,34 @@ def test_feasible_sets_on_fast_kernel(gpu, oracle, B, d, N):
     for b in range(0, B, 7):
         w = oracle.Wrapper(data["coef"][b], data["breaks"], data["grid"], data["vlim"][b], data["alim"][b])
         assert np.array_equal(X[b], w.compute_feasible_sets(), equal_nan=True), b
+
+
+def test_headline_batch_oracle_parity_every_trajectory(gpu, oracle):
+    """All 65 536 trajectories of the headline batch, and an irregular batch of the same size (asymmetric
+    and positive lower velocity limits, standing joints, non-uniform knots and grid, boundary velocities),
+    against the oracle on every host thread: identical bits, trajectory by trajectory."""
+    B, d, N = 65536, 7, 200
+    data = batch.make_synthetic_batch(B, d, N)
+    cases = [(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], None, None)]
+    rng = np.random.default_rng(4242)
+    nw = 6
+    knots = np.concatenate([[0.0], np.sort(rng.random(nw - 2)) * 0.9 + 0.05, [1.0]])
+    way = rng.standard_normal((B, nw, d))
+    still = rng.random((B, d)) < 0.08
+    way = np.where(still[:, None, :], way[:, :1, :], way)
+    coef, breaks = batch.spline_coefficients(knots, way)
+    grid = 0.6 * np.concatenate([[0.0], np.sort(rng.random(N - 1)), [1.0]]) + 0.4 * np.linspace(0, 1, N + 1)
+    vhi = 5 + 25 * rng.random((B, d)); vlo = -(5 + 25 * rng.random((B, d)))
+    vlo = np.where(rng.random((B, d)) < 0.01, 0.05 * rng.random((B, d)), vlo)
+    ahi = 5 + 10 * rng.random((B, d)); alo = -(5 + 10 * rng.random((B, d)))
+    sd0 = np.where(rng.random(B) < 0.4, 0.3 * rng.random(B), 0.0)
+    sd1 = np.where(rng.random(B) < 0.4, 0.3 * rng.random(B), 0.0)
+    cases.append((coef, breaks, grid, np.ascontiguousarray(np.stack([vlo, vhi], -1)),
+                  np.ascontiguousarray(np.stack([alo, ahi], -1)), sd0, sd1))
+    for ci, args in enumerate(cases):
+        got = batch.solve_batch(*args)
+        ref = oracle.solve_batch(*args, nthreads=0)
+        assert np.array_equal(got["status"], ref["status"]), ci
+        assert len(np.unique(ref["status"])) >= (1 if ci == 0 else 2)
+        for k in ("K", "sd2", "u"):
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (ci, k)
