@@ -47,6 +47,42 @@ def test_parameterization_matches_reference(reference, oracle, d, N, scheme, sd)
         assert sw.get_no_stages() == N
 
 
+@pytest.mark.parametrize("d,N,nway,seed", [(6, 90, 9, 1), (7, 120, 6, 2), (9, 50, 7, 3), (14, 40, 5, 4), (3, 150, 4, 5)])
+def test_irregular_problems_match_reference(reference, oracle, d, N, nway, seed):
+    """Asymmetric limits incl. positive lower velocity limits, joints that stand still, non-uniform knots
+    and grids, non-zero boundary velocities, up to 14 dof: the oracle against the live reference."""
+    import toppra.algorithm as algo
+    import toppra.constraint as constraint
+    rng = np.random.default_rng(9000 + seed)
+    knots = np.concatenate([[0.0], np.sort(rng.random(nway - 2)) * 0.9 + 0.05, [1.0]])
+    grid = 0.6 * np.concatenate([[0.0], np.sort(rng.random(N - 1)), [1.0]]) + 0.4 * np.linspace(0, 1, N + 1)
+    seen = set()
+    for _ in range(10):
+        way = rng.standard_normal((nway, d))
+        still = rng.random(d) < 0.15
+        way = np.where(still[None, :], way[:1, :], way)
+        vhi = 5 + 25 * rng.random(d); vlo = -(5 + 25 * rng.random(d))
+        vlo = np.where(rng.random(d) < 0.05, 0.05 * rng.random(d), vlo)
+        ahi = 5 + 10 * rng.random(d); alo = -(5 + 10 * rng.random(d))
+        vl, al = np.stack([vlo, vhi], 1), np.stack([alo, ahi], 1)
+        sd0 = 0.3 * rng.random() if rng.random() < 0.5 else 0.0
+        sd1 = 0.3 * rng.random() if rng.random() < 0.5 else 0.0
+        path = reference.SplineInterpolator(knots, way)
+        cons = [constraint.JointVelocityConstraint(vl), constraint.JointAccelerationConstraint(al)]
+        inst = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        sdd, sdv, _, K = inst.compute_parameterization(sd0, sd1, return_data=True)
+        w = oracle.Wrapper(path.cspl.c, path.cspl.x, grid, vl, al)
+        st, osdd, osd, oxs, oK = w.compute_parameterization(sd0, sd1)
+        assert_same(oK, K, "K")
+        seen.add(st)
+        if sdv is None:
+            assert st == 1
+        else:
+            assert_same(osd, sdv, "sd")
+            assert_same(osdd, sdd, "sdd")
+    assert 0 in seen
+
+
 def test_lp2d_matches_reference(reference, oracle):
     import toppra.solverwrapper.cy_seidel_solverwrapper as seidel
     for seed in range(300):
