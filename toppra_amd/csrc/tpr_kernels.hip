@@ -376,6 +376,21 @@ int tpr_init(int device) {
     return TPR_E_OK;
 }
 
+#ifdef TPR_DEBUG_PREDICT  // debug builds only: read and clear the walk's give-up counters
+int tpr_debug_walk_fail(unsigned long long *out16) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(tpr::g_walk_fail), 16 * sizeof(unsigned long long)));
+    unsigned long long zero[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(tpr::g_walk_fail), zero, sizeof(zero)));
+    return TPR_E_OK;
+}
+int tpr_debug_walk_hist(unsigned int *out4x512) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out4x512, HIP_SYMBOL(tpr::g_walk_hist), 5 * 512 * sizeof(unsigned int)));
+    return TPR_E_OK;
+}
+#endif
+
 int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream_) {
     if (int rc = check_problem(p)) return rc;
     if (!r || !r->K) return fail(TPR_E_BADARG, "result.K is required");
