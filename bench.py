@@ -84,8 +84,84 @@ def cpu_baseline(data, target_seconds=12.0):
     return {"value": n * reps / total, "unit": "trajectories/s", "cores": cores, "kind": "port",
             "sample": "first %d trajectories of the rank-0 batch x %d passes (%.1f s), oracle/seidel_oracle.c "
                       "(C restatement of the reference's seidel path, bit-exact with it) with OpenMP over "
-                      "%d threads; the reference itself (Python+Cython) measured 180 traj/s/core in the "
-                      "build container (BASELINE.md)" % (n, reps, total, cores)}
+                      "%d threads" % (n, reps, total, cores),
+            "reference_itself": {
+                "value": 180.0, "unit": "trajectories/s per core", "where": "build container, 1 core, Python+Cython seidel",
+                "note": "the reference cannot run on the GPU box: /root/reference is absent there and its sources may not be "
+                        "copied into this repository, so the timed baseline is the C port (which is ~25x faster per core "
+                        "than the reference because it has no Python call overhead -- a stronger baseline)"}}
+
+
+def baseline_configs(torch, tb, dev):
+    """Every configuration of BASELINE.json.configs in one place (rank 0, N=1, outside the timed region):
+    C1 latency through the drop-in class, C2 / C3 / C4 kernel times with inputs resident in HBM, and the
+    PCIe-inclusive time of the host-buffer entry for the headline shape."""
+    import toppra_amd as ta
+
+    def dev_args(data):
+        return [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]
+
+    def kernel(B, d, N, reps=5):
+        data = tb.make_synthetic_batch(B, d, N)
+        dv = dev_args(data)
+        out = tb.solve_batch(*dv)
+        torch.cuda.synchronize()
+        ms = tb.solve_batch_timed(*dv, out, reps=reps)
+        nseg = data["coef"].shape[2]
+        gbs = algorithmic_bytes(d, N, nseg) * B / (ms * 1e-3) / 1e9
+        return {"batch": B, "dof": d, "gridpoints": N, "kernel_ms": ms, "trajectories_per_s": B / ms * 1e3,
+                "waypoint_lps_per_s": 3 * N * B / ms * 1e3, "ok_fraction": float((out["status"] == 0).double().mean().item()),
+                "algorithmic_bytes_per_trajectory": algorithmic_bytes(d, N, nseg), "achieved_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+
+    def wall(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts) * 1e3)
+
+    res = {}
+    # C1: examples/plot_kinematics.py -- one 7-dof spline through the reference's own class surface
+    np.random.seed(9)
+    way = np.random.randn(5, 7)
+    path = ta.SplineInterpolator(np.linspace(0, 1, 5), way)
+    vlim_ = 10 + np.random.rand(7) * 20
+    alim_ = 10 + np.random.rand(7) * 2
+    cons = [ta.constraint.JointVelocityConstraint(np.vstack((-vlim_, vlim_)).T),
+            ta.constraint.JointAccelerationConstraint(np.vstack((-alim_, alim_)).T)]
+    c1 = {}
+    for label, grid in (("auto_grid", None), ("N100", np.linspace(0, 1, 101))):
+        inst = ta.algorithm.TOPPRA(cons, path, gridpoints=grid)
+        ms = wall(lambda: inst.compute_parameterization(0, 0), 20)
+        c1[label] = {"gridpoints": int(len(inst.problem_data.gridpoints) - 1), "compute_parameterization_ms": ms,
+                     "return_code": str(inst.problem_data.return_code.name)}
+    c1["note"] = ("single trajectory, host arrays in and out through toppra_amd.algorithm.TOPPRA (one launch per pass); "
+                  "latency floor of a 1-trajectory launch, not a throughput figure.  Reference (Python+Cython seidel, "
+                  "build container, 1 core): ~3.9 ms for the auto grid")
+    res["C1_single_trajectory"] = c1
+    res["C2_batch4096_d7_N200"] = kernel(4096, 7, 200)
+    res["C3_batch65536_d6_N500"] = kernel(65536, 6, 500, reps=3)
+    data4 = tb.make_synthetic_batch(16384, 7, 100)
+    dv4 = dev_args(data4)
+    ell = [1e-3, 5e-2, 9e-3]  # examples/plot_robust_kinematics.py:26-28
+    ms4 = wall(lambda: tb.robust_solve_batch(*dv4, ell), 3)
+    res["C4_robust_batch16384_d7_N100"] = {
+        "batch": 16384, "dof": 7, "gridpoints": 100, "ms": ms4, "trajectories_per_s": 16384 / ms4 * 1e3,
+        "note": "RobustLinearConstraint over JointAcceleration, ellipsoid (1e-3, 5e-2, 9e-3); the reference's ECOS stage "
+                "problems solved exactly; parity pinned to an independent SOCP solver at 1e-7 (tests/test_gpu_robust.py)"}
+    res["C5_batch524288_8gpu"] = "this bench with --gpus 8 (65536 trajectories per rank + RCCL gather of sd^2)"
+    # PCIe-inclusive: numpy in -> numpy out through the host-buffer entry (H2D 59 MB, kernel, D2H)
+    datah = tb.make_synthetic_batch(65536, 7, 200)
+    hargs = [datah[k] for k in ("coef", "breaks", "grid", "vlim", "alim")]
+    res["host_buffers_65536x7x200"] = {
+        "all_outputs_ms": wall(lambda: tb.solve_batch(*hargs), 3),
+        "without_K_ms": wall(lambda: tb.solve_batch(*hargs, want_K=False), 3),
+        "note": "PCIe-inclusive wall time of tpr_solve_batch with host pointers (page-locked result arrays); never `value`"}
+    return res
 
 
 def main():
@@ -99,6 +175,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=5)
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs block (C1-C4, host-buffer path)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary (full iteration, family 2) measurements (used under rocprofv3 so that the "
                          "kernel statistics cover the headline mode only)")
@@ -177,6 +254,25 @@ def main():
                                           reps=reps, variant=2)
     ok_frac = float((out["status"] == 0).double().mean().item())
 
+    # multi-GPU: what each rank's kernel took and what the gather costs on its own (outside the timed region),
+    # so that an N > 1 line explains itself
+    per_rank_kernel_ms = gather_alone_ms = None
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = kernel_ms
+        dist.all_reduce(t)
+        per_rank_kernel_ms = [float(v) for v in t.tolist()]
+        g2 = PipelinedGather(B, N + 1, torch.float64, dev)
+        g2.submit(out["sd2"]); g2.finish(); torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            g2.submit(out["sd2"])
+            g2.finish()
+        torch.cuda.synchronize()
+        tg = torch.tensor([(time.perf_counter() - t0) / 5 * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_alone_ms = float(tg.item())
+
     if rank == 0:
         bytes_per_traj = algorithmic_bytes(d, N, nseg)
         achieved = bytes_per_traj * B / (kernel_ms * 1e-3) / 1e9
@@ -203,6 +299,8 @@ def main():
                 "kernel_variant": args.variant,
             },
             "waypoint_lps_per_s": 3 * N * traj_per_s,
+            "per_rank_kernel_ms": per_rank_kernel_ms,
+            "gather_alone_ms": gather_alone_ms,
             "secondary_measured": (not args.no_secondary) and world == 1,
             "full_iteration": {
                 "note": "TPR_STRICT_SEIDEL: every stage LP through the reference's full Seidel iteration (kernel "
@@ -224,7 +322,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc["gbps"] if pmc else None,
+                "traffic": pmc["bytes_per_launch"] if pmc else None,
+                "algorithmic_bytes_per_launch": bytes_per_traj * B,
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_trajectory": bytes_per_traj,
                 "pmc": pmc,
@@ -232,6 +331,8 @@ def main():
                         "latencies -- not by HBM: DESIGN.md section 3.5",
             },
         }
+        if not args.no_configs and world == 1:
+            line["configs"] = baseline_configs(torch, tb, dev)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline(data)
         print(json.dumps(line))

@@ -43,11 +43,7 @@ extern "C" {
 #define TPR_DEVICE_PTRS 8
 #define TPR_BREAKS_PER_TRAJ 16
 #define TPR_GRID_PER_TRAJ 32
-/* Opt-in: skip the lower-bound LP of a backward stage when (u, x) = (0, 0) is provably feasible, i.e.
- * the lower controllable bound is exactly 0 (the reference computes 0 up to ~1e-16 rounding noise).
- * Results stay within ~1e-13 of the reference (bound asserted in the tests: 1e-8) instead of being
- * bit-identical.  Honoured by the rows-across-lanes kernels; ignored elsewhere.                    */
-#define TPR_RELAXED_LOWER 64
+/* bit 64 is reserved (it selected an approximate mode in round 1, retired: every path is bit-exact now) */
 /* Force every stage LP through the full Seidel iteration (served by the rows-across-lanes kernels).
  * By default the fast kernels answer a backward LP from a verified optimal vertex -- found as "x on its
  * box bound, u on the tightest row" (lower bound) or as the previous stage's active pair, if need be
@@ -87,12 +83,17 @@ typedef struct tpr_result {
     double *sd2;     /* [B][N+1]    x_i = sd_i^2           (may be NULL)                          */
     double *sd;      /* [B][N+1]    sd_vec = sqrt(x)       (may be NULL)                          */
     double *u;       /* [B][N]      sdd_vec                (may be NULL)                          */
-    double *K;       /* [B][N+1][2] controllable sets      (REQUIRED: the forward scan reads it)  */
+    double *K;       /* [B][N+1][2] controllable sets      (may be NULL for tpr_solve_batch: kept in
+                                                            a stream-ordered workspace then)        */
     int32_t *status; /* [B]                                (may be NULL)                          */
 } tpr_result;
 
-/* Library / device management.  tpr_init selects the HIP device (hipSetDevice) and must succeed
- * before any other call; it fails (TPR_E_HIP) when no gfx950 device is visible.                 */
+/* Library / device management.  tpr_init(device) verifies that `device` is a gfx950 GPU and makes it
+ * the default device of host-pointer calls; it must succeed once before any other call and fails
+ * (TPR_E_HIP / TPR_E_UNSUPPORTED) otherwise.  The calling thread's current HIP device is NOT changed:
+ * every entry point runs on the device its data lives on -- the device of the pointers with
+ * TPR_DEVICE_PTRS, the tpr_init device otherwise -- and restores the caller's device on return, so
+ * the library is safe next to frameworks (torch) that move the per-thread current device.        */
 int tpr_init(int device);
 int tpr_device_count(void);
 const char *tpr_last_error(void);

@@ -6,6 +6,7 @@ import pytest
 
 import toppra_amd as ta
 from tests.helpers import assert_same, golden
+from toppra_amd import batch
 from toppra_amd.algorithm import ParameterizationReturnCode
 
 pytestmark = pytest.mark.gpu
@@ -161,3 +162,31 @@ def test_robust_constraint_params(gpu, example, scheme):
     assert rc.get_constraint_type() == ta.constraint.ConstraintType.CanonicalConic
     with pytest.raises(AssertionError):  # as in the reference: seidel cannot take conic constraints
         ta.algorithm.TOPPRA([pc_vel, rc], path, gridpoints=fx["n100_grid"], solver_wrapper="seidel")
+
+
+def test_K_is_optional_and_inputs_are_validated(gpu):
+    """tpr_result.K == NULL keeps the controllable sets in a workspace (same sd2 / u / status bits);
+    mistyped or misplaced device tensors are refused instead of being read as raw fp64 pointers."""
+    import torch
+    data = batch.make_synthetic_batch(300, 5, 40, seed=11)
+    args = (data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    full = batch.solve_batch(*args)
+    for variant in (0, 2, 3):
+        lean = batch.solve_batch(*args, want_K=False, variant=variant)
+        assert "K" not in lean
+        for k in ("sd2", "u", "status"):
+            assert np.array_equal(lean[k], full[k], equal_nan=True), (variant, k)
+    scalar = batch.solve_batch(*args, sd_start=0.0, sd_end=0.05)           # scalars broadcast to [B]
+    vec = batch.solve_batch(*args, sd_start=np.zeros(300), sd_end=np.full(300, 0.05))
+    assert np.array_equal(scalar["sd2"], vec["sd2"], equal_nan=True)
+    dev = torch.device("cuda", 0)
+    dv = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in args]
+    torch.cuda.set_device(0)
+    got = batch.solve_batch(*dv)
+    assert np.array_equal(got["sd2"].cpu().numpy(), full["sd2"], equal_nan=True)
+    with pytest.raises(ValueError):
+        batch.solve_batch(dv[0].float(), *dv[1:])                            # fp32 tensor
+    with pytest.raises(ValueError):
+        batch.solve_batch(dv[0], dv[1], dv[2], dv[3].cpu(), dv[4])           # host tensor mixed in
+    with pytest.raises(ValueError):
+        batch.solve_batch(*dv, sd_end=torch.zeros(7, dtype=torch.float64, device=dev))

@@ -19,7 +19,6 @@ ACC_INTERPOLATION = 4
 DEVICE_PTRS = 8
 BREAKS_PER_TRAJ = 16
 GRID_PER_TRAJ = 32
-RELAXED_LOWER = 64
 STRICT_SEIDEL = 128
 
 STATUS_OK, STATUS_FAIL_UNCONTROLLABLE, STATUS_ERR_UNKNOWN = 0, 1, 2
@@ -131,16 +130,18 @@ def check(rc):
 
 
 def init(device=None):
-    """Select the HIP device; raises ToppraHipError when no gfx950 device is usable."""
+    """Select the HIP device for the calling thread; raises ToppraHipError when no gfx950 device is
+    usable.  HIP's current device is per thread and torch moves it (``torch.cuda.set_device``, device
+    contexts), so this is called on EVERY entry with the device the call's tensors live on -- it is one
+    ``hipSetDevice`` plus, the first time a device is seen, the gfx950 check.  ``device=None``: the
+    device of the last call, or LOCAL_RANK on the first."""
     global _inited_device
     L = load()
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0")) if _inited_device is None else _inited_device
-    if _inited_device == device:
-        return device
     check(L.tpr_init(int(device)))
-    _inited_device = device
-    return device
+    _inited_device = int(device)
+    return _inited_device
 
 
 def device_count():
@@ -166,21 +167,78 @@ def ptr(x):
     return x.data_ptr()
 
 
+def _per_traj(name, arr, B, like, dev):
+    """A per-trajectory vector ([B], or a scalar broadcast to it) as a contiguous fp64 array on the
+    problem's device."""
+    if dev:
+        import torch
+        if not (hasattr(arr, "is_cuda") and arr.is_cuda):
+            arr = torch.as_tensor(arr, dtype=torch.float64, device=like.device)
+        check_tensor(name, arr, like)
+        if arr.ndim == 0:
+            arr = arr.expand(B)
+        if tuple(arr.shape) != (B,):
+            raise ValueError("%s must be a scalar or have shape [B] = [%d], got %s" % (name, B, tuple(arr.shape)))
+        return arr.contiguous()
+    arr = np.asarray(arr, dtype=np.float64)
+    if arr.ndim == 0:
+        arr = np.broadcast_to(arr, (B,))
+    if arr.shape != (B,):
+        raise ValueError("%s must be a scalar or have shape [B] = [%d], got %s" % (name, B, arr.shape))
+    return np.ascontiguousarray(arr)
+
+
+def check_tensor(name, t, like):
+    """Device tensors are passed to the kernels as raw pointers: they must be fp64 and live on the
+    same device as ``coef``."""
+    import torch
+    if t.dtype != torch.float64:
+        raise ValueError("%s must be float64 (got %s): the kernels read raw fp64 pointers" % (name, t.dtype))
+    if not t.is_cuda or t.device != like.device:
+        raise ValueError("%s must live on %s like coef (got %s)" % (name, like.device, t.device))
+
+
+def per_traj_vector(name, arr, B, like):
+    """Public form of the per-trajectory check for the other batch entries (sdmin, sdmax, ...)."""
+    return _per_traj(name, arr, B, like, is_torch_cuda(like))
+
+
 def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
-                 variant=0, keep=None, relaxed=False, strict=False):
+                 variant=0, keep=None, strict=False):
     """Build a tpr_problem from arrays (all numpy or all torch-CUDA).  `keep` collects the
-    converted arrays so they outlive the call."""
+    converted arrays so they outlive the call.  Shapes and dtypes are validated here -- the C-ABI
+    takes raw pointers and sizes, so a short or mistyped array would be read out of bounds:
+    coef [B,4,nseg,d]; breaks [nseg+1] or [B,nseg+1]; grid [N+1] or [B,N+1] (strictly increasing);
+    vlim/alim [B,d,2]; sd_start/sd_end scalars or [B].  Device tensors must be float64 on coef's device."""
     dev = is_torch_cuda(coef)
-    conv = (lambda x: x.contiguous()) if dev else f64
     keep = keep if keep is not None else []
-    coef = conv(coef)
-    breaks = conv(breaks)
-    grid = conv(grid)
+    if dev:
+        def conv(name, x):
+            if not (hasattr(x, "is_cuda") and x.is_cuda):
+                raise ValueError("%s must be a CUDA tensor like coef (mixing host and device arrays is not supported)" % name)
+            check_tensor(name, x, coef)
+            return x.contiguous()
+        check_tensor("coef", coef, coef)
+        coef = coef.contiguous()
+    else:
+        def conv(name, x):
+            return f64(x)
+        coef = f64(coef)
+    breaks = conv("breaks", breaks)
+    grid = conv("grid", grid)
     if coef.ndim != 4 or coef.shape[1] != 4:
         raise ValueError("coef must have shape [B, 4, nseg, d]")
     B, _, nseg, d = (int(s) for s in coef.shape)
+    if grid.ndim not in (1, 2) or (grid.ndim == 2 and int(grid.shape[0]) != B):
+        raise ValueError("grid must have shape [N+1] or [B, N+1] with B = %d, got %s" % (B, tuple(grid.shape)))
+    if breaks.ndim not in (1, 2) or (breaks.ndim == 2 and int(breaks.shape[0]) != B):
+        raise ValueError("breaks must have shape [nseg+1] or [B, nseg+1] with B = %d, got %s" % (B, tuple(breaks.shape)))
     N = int(grid.shape[-1]) - 1
-    flags = (DEVICE_PTRS if dev else 0) | (RELAXED_LOWER if relaxed else 0) | (STRICT_SEIDEL if strict else 0)
+    if N < 1:
+        raise ValueError("grid needs at least two gridpoints")
+    if not dev and not np.all(np.diff(grid, axis=-1) > 0):  # device grids are the caller's responsibility
+        raise ValueError("grid must be strictly increasing")
+    flags = (DEVICE_PTRS if dev else 0) | (STRICT_SEIDEL if strict else 0)
     if breaks.ndim == 2:
         flags |= BREAKS_PER_TRAJ
     if grid.ndim == 2:
@@ -192,9 +250,9 @@ def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, int
     p.coef, p.breaks, p.grid = ptr(coef), ptr(breaks), ptr(grid)
     for name, arr, flag in (("vlim", vlim, HAS_VELOCITY), ("alim", alim, HAS_ACCELERATION)):
         if arr is not None:
-            arr = conv(arr)
+            arr = conv(name, arr)
             if tuple(arr.shape) != (B, d, 2):
-                raise ValueError("%s must have shape [B, d, 2]" % name)
+                raise ValueError("%s must have shape [B, d, 2] = [%d, %d, 2], got %s" % (name, B, d, tuple(arr.shape)))
             keep.append(arr)
             setattr(p, name, ptr(arr))
             flags |= flag
@@ -202,7 +260,7 @@ def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, int
         flags |= ACC_INTERPOLATION
     for name, arr in (("sd_start", sd_start), ("sd_end", sd_end)):
         if arr is not None:
-            arr = conv(arr)
+            arr = _per_traj(name, arr, B, coef, dev)
             keep.append(arr)
             setattr(p, name, ptr(arr))
     p.flags = flags

@@ -238,16 +238,11 @@ class BatchTOPPRA(object):
             gridpoints = np.asarray(gridpoints, dtype=np.float64)
         return cls(coef, breaks, gridpoints, vlim, alim, **kw)
 
-    def compute_parameterization(self, sd_start=None, sd_end=None, want_sd=True, variant=0, relaxed=False):
+    def compute_parameterization(self, sd_start=None, sd_end=None, want_sd=True, variant=0):
         """dict(sd2, sd, u, K, status): per-trajectory results; status 0/1/2 = Ok /
-        FailUncontrollable / ErrUnknown, failed rows NaN-filled.
-
-        ``relaxed=True`` skips the backward lower-bound LPs whose answer is provably zero (about
-        half of all stage LPs, ~2x faster); sd/u then match the reference within 1e-8 (identical on
-        every fixture) while the lower controllable bound loses the reference's ~1e-16 noise."""
+        FailUncontrollable / ErrUnknown, failed rows NaN-filled."""
         return _batch.solve_batch(self.coef, self.breaks, self.gridpoints, self.vlim, self.alim,
-                                  sd_start, sd_end, self.interpolation, want_sd=want_sd, variant=variant,
-                                  relaxed=relaxed)
+                                  sd_start, sd_end, self.interpolation, want_sd=want_sd, variant=variant)
 
     def compute_parameterization_sd(self, desired_duration, sd_start=None, sd_end=None, atol=1e-5):
         """TOPPRAsd for the batch: dict(sd2, sd, u, K, status, alpha)."""

@@ -56,25 +56,27 @@ def _prepare(coef):
 
 
 def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
-                want_sd=False, variant=0, relaxed=False, strict=False):
+                want_sd=False, variant=0, strict=False, want_K=True):
     """compute_parameterization for B trajectories.
 
     Returns dict(sd2[B,N+1], u[B,N], K[B,N+1,2], status[B] (+ sd[B,N+1] if want_sd)); failed
     trajectories are NaN-filled with status 1 (FailUncontrollable) or 2 (ErrUnknown).
+    ``want_K=False`` leaves the controllable sets in a device workspace (half of the output bytes of a
+    host-buffer call).
 
-    ``relaxed=True`` (TPR_RELAXED_LOWER) skips backward lower-bound LPs whose answer is provably 0;
-    results then agree with the reference to ~1e-13 instead of bit for bit.  ``strict=True``
-    (TPR_STRICT_SEIDEL) disables the certified shortcut of the lower-bound LP (same bits, slower)."""
+    ``strict=True`` (TPR_STRICT_SEIDEL) runs every stage LP through the reference's full Seidel
+    iteration instead of answering it from a certified optimal vertex (same bits, slower)."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
-                                 variant, relaxed=relaxed, strict=strict)
+                                 variant, strict=strict)
     B, N = p.B, p.N
-    out = {"sd2": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)),
-           "K": _empty(coef, (B, N + 1, 2)), "status": _empty(coef, (B,), "i32")}
+    out = {"sd2": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)), "status": _empty(coef, (B,), "i32")}
+    if want_K:
+        out["K"] = _empty(coef, (B, N + 1, 2))
     if want_sd:
         out["sd"] = _empty(coef, (B, N + 1))
     r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out["u"]),
-                         K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
+                         K=_capi.ptr(out.get("K")), status=_capi.ptr(out["status"]))
     _capi.check(_capi.load().tpr_solve_batch(C.byref(p), C.byref(r), _stream_ptr(coef)))
     return out
 
@@ -88,12 +90,7 @@ def solve_desired_duration_batch(coef, breaks, grid, vlim, alim, desired_duratio
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, True)
     B, N = p.B, p.N
-    dev = _capi.is_torch_cuda(coef)
-    if dev:
-        import torch
-        desired = torch.as_tensor(desired_duration, dtype=torch.float64, device=coef.device).expand(B).contiguous()
-    else:
-        desired = np.ascontiguousarray(np.broadcast_to(np.asarray(desired_duration, dtype=np.float64), (B,)))
+    desired = _capi.per_traj_vector("desired_duration", desired_duration, B, coef)
     out = {"sd2": _empty(coef, (B, N + 1)), "sd": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)),
            "K": _empty(coef, (B, N + 1, 2)), "status": _empty(coef, (B,), "i32"), "alpha": _empty(coef, (B,))}
     r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out["sd"]), u=_capi.ptr(out["u"]),
@@ -125,12 +122,12 @@ def robust_solve_batch(coef, breaks, grid, vlim, alim, ellipsoid, sd_start=None,
 
 
 def solve_batch_timed(coef, breaks, grid, vlim, alim, out, reps, sd_start=None, sd_end=None,
-                      interpolation=True, variant=0, relaxed=False, strict=False):
+                      interpolation=True, variant=0, strict=False):
     """bench.py helper: `reps` launches between two hipEvents on torch's current stream.
     Returns average ms per launch.  `out` is a dict from a previous solve_batch (device)."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
-                                 variant, relaxed=relaxed, strict=strict)
+                                 variant, strict=strict)
     r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out["u"]),
                          K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
     ms = C.c_float(0)
@@ -143,9 +140,8 @@ def controllable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interp
     """compute_controllable_sets(sdmin, sdmax) for B trajectories -> K[B,N+1,2]."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation)
-    dev = _capi.is_torch_cuda(coef)
-    conv = (lambda x: x.contiguous()) if dev else _capi.f64
-    sdmin, sdmax = conv(sdmin), conv(sdmax)
+    sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, coef)
+    sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, coef)
     K = _empty(coef, (p.B, p.N + 1, 2))
     _capi.check(_capi.load().tpr_controllable_sets_batch(C.byref(p), _capi.ptr(sdmin), _capi.ptr(sdmax),
                                                          _capi.ptr(K), _stream_ptr(coef)))

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -21,7 +22,33 @@
 namespace {
 
 thread_local std::string g_err;
-int g_device = -1;
+int g_device = -1;             // default device of host-pointer calls (last successful tpr_init)
+bool g_checked[64] = {false};  // devices already verified to be gfx950
+
+// HIP's current device is per thread and other libraries (torch) move it.  Every entry point runs on
+// the device its data lives on -- the device of the pointers with TPR_DEVICE_PTRS, the tpr_init()
+// device otherwise -- and puts the caller's current device back on return.
+struct DeviceScope {
+    int prev = -1, dev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int want) : dev(want) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceScope() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
+// Device a call should run on: the one `device_ptr` lives on (TPR_DEVICE_PTRS), else g_device.
+int call_device(bool device_ptrs, const void *device_ptr) {
+    if (device_ptrs && device_ptr) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, device_ptr) == hipSuccess && attr.device >= 0) return attr.device;
+        (void)hipGetLastError();
+    }
+    return g_device;
+}
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -134,7 +161,9 @@ int launch_group(const tpr::BatchArgs &A, hipStream_t stream) {
                      A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status, A.sd_end_hi, A.backward_only};
     const int groups = threads / L;
     size_t lds = group_lds_bytes<D, L>(A.nseg, threads, table_in_lds);
-    if (const char *pad = std::getenv("TPR_LDS_PAD")) lds += (size_t)std::atoi(pad);  // occupancy experiments
+#ifdef TPR_LDS_PAD_EXPERIMENT  // occupancy experiments (development builds only)
+    if (const char *pad = std::getenv("TPR_LDS_PAD")) lds += (size_t)std::atoi(pad);
+#endif
     const dim3 grid((A.B + groups - 1) / groups), block(threads);
     if (table_in_lds) hipLaunchKernelGGL((tpr::group_solve_kernel<D, L, true>), grid, block, lds, stream, G);
     else hipLaunchKernelGGL((tpr::group_solve_kernel<D, L, false>), grid, block, lds, stream, G);
@@ -187,9 +216,9 @@ int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
 }
 
 // The certified lane kernel (family 3) serves the same constraint set up to 8 dof when sd2, u and
-// status are requested; the strict and relaxed modes stay with family 2.
+// status are requested; the strict mode stays with family 2.
 bool cert_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && A.d <= 8 && !(A.flags & (TPR_STRICT_SEIDEL | TPR_RELAXED_LOWER)) && A.N >= 1 &&
+    return group_supported(A) && A.d <= 8 && !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
            (A.backward_only || (A.sd2 && A.u && A.status));
 }
 
@@ -366,13 +395,15 @@ int tpr_init(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(TPR_E_HIP, "no HIP device visible");
-    if (device < 0 || device >= n) return fail(TPR_E_BADARG, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(TPR_E_UNSUPPORTED, std::string("this library is built for gfx950 only, found ") + prop.gcnArchName);
-    g_device = device;
+    if (device < 0 || device >= n || device >= 64) return fail(TPR_E_BADARG, "device index out of range");
+    if (!g_checked[device]) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(TPR_E_UNSUPPORTED, std::string("this library is built for gfx950 only, found ") + prop.gcnArchName);
+        g_checked[device] = true;
+    }
+    g_device = device;  // the caller's current device is left alone: every entry scopes its own (DeviceScope)
     return TPR_E_OK;
 }
 
@@ -393,16 +424,27 @@ int tpr_debug_walk_hist(unsigned int *out4x512) {
 
 int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream_) {
     if (int rc = check_problem(p)) return rc;
-    if (!r || !r->K) return fail(TPR_E_BADARG, "result.K is required");
+    if (!r) return fail(TPR_E_BADARG, "null result");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     const size_t B = (size_t)p->B, N = (size_t)p->N;
     A.sd2 = S.out(r->sd2, B * (N + 1));
     A.sd = S.out(r->sd, B * (N + 1));
     A.u = S.out(r->u, B * N);
-    A.K = S.out(r->K, B * (N + 1) * 2);
     A.status = S.out(r->status, B);
+    if (r->K) {
+        A.K = S.out(r->K, B * (N + 1) * 2);
+    } else if (B > 0) {
+        // the caller does not want the controllable sets: the forward scan still reads them, so they live in
+        // a stream-ordered workspace (no host copy, no caller buffer; half of the output bytes of a host call)
+        void *ws = nullptr;
+        if (S.err == hipSuccess) S.err = hipMallocAsync(&ws, B * (N + 1) * 2 * sizeof(double), stream);
+        if (S.err == hipSuccess) S.owned.push_back(ws);
+        A.K = static_cast<double *>(ws);
+    }
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (int rc = launch_solve(p, A, stream)) return rc;
     HIP_TRY(S.finish());
@@ -414,6 +456,8 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
     if (int rc = check_problem(p)) return rc;
     if (!r || !r->K || !desired) return fail(TPR_E_BADARG, "result.K and desired are required");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "TOPPRAsd needs an acceleration constraint with Interpolation");
@@ -461,6 +505,8 @@ int tpr_robust_solve_batch(const tpr_problem *p, const double *ellipsoid, const 
     if (!(p->flags & TPR_HAS_ACCELERATION)) return fail(TPR_E_BADARG, "the robust path needs an acceleration constraint");
     if (ellipsoid[0] < 0 || ellipsoid[1] < 0 || ellipsoid[2] < 0) return fail(TPR_E_BADARG, "ellipsoid axes must be non-negative");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::RobustArgs P{};
     P.A = stage_problem(p, S);
@@ -490,6 +536,8 @@ int tpr_solve_batch_timed(const tpr_problem *p, const tpr_result *r, void *strea
     if (!(p->flags & TPR_DEVICE_PTRS)) return fail(TPR_E_BADARG, "timed entry needs TPR_DEVICE_PTRS");
     if (!r || !r->K || reps < 1 || !ms_per_launch) return fail(TPR_E_BADARG, "bad timed arguments");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(true, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     A.sd2 = r->sd2; A.sd = r->sd; A.u = r->u; A.K = r->K; A.status = r->status;
@@ -515,6 +563,8 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
     if (int rc = check_problem(p)) return rc;
     if (!sdmin || !sdmax || !K) return fail(TPR_E_BADARG, "sdmin/sdmax/K are required");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     const size_t B = (size_t)p->B, N = (size_t)p->N;
@@ -540,6 +590,8 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
     if (int rc = check_problem(p)) return rc;
     if (!X) return fail(TPR_E_BADARG, "X is required");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     double *dX = S.out(X, (size_t)p->B * (p->N + 1) * 2);
@@ -559,6 +611,8 @@ int tpr_constraint_params_batch(const tpr_problem *p, double *a, double *b, doub
                                 double *high, double *xbound, double *qs, double *qss, void *stream_) {
     if (int rc = check_problem(p)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     const size_t pts = (size_t)p->B * (p->N + 1), nC = (size_t)rows_per_lp(p);
@@ -579,6 +633,8 @@ int tpr_solve_stagewise_batch(const tpr_problem *p, const int32_t *stage, const 
     if (int rc = check_problem(p)) return rc;
     if (!stage || !g || !xb || !active || !out) return fail(TPR_E_BADARG, "null stagewise argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     const size_t B = (size_t)p->B;
@@ -598,6 +654,8 @@ int tpr_const_accel_times_batch(const tpr_problem *p, const double *sd, double *
     if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
     if (!p || p->B < 0 || p->N < 1 || !p->grid || !sd || !ts) return fail(TPR_E_BADARG, "bad const-accel arguments");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->grid));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     const size_t B = (size_t)p->B, N = (size_t)p->N;
     tpr::ParamArgs A{};
@@ -619,6 +677,8 @@ int tpr_const_accel_eval_batch(const tpr_problem *p, const double *sd, const dou
         !us || !times || !out || T < 0 || order < 0 || order > 2)
         return fail(TPR_E_BADARG, "bad const-accel eval arguments");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     const size_t B = (size_t)p->B, N = (size_t)p->N, d = (size_t)p->d, nseg = (size_t)p->nseg;
     tpr::EvalArgs A{};
@@ -647,6 +707,8 @@ int tpr_spline_fit_batch(int B, int m, int d, const double *knots, int knots_per
         return fail(TPR_E_BADARG, "spline fit needs 2 <= m <= 64 waypoints, knots, waypoints, coef");
     if (bc_start < 0 || bc_start > 2 || bc_end < 0 || bc_end > 2) return fail(TPR_E_BADARG, "unknown boundary condition");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(device_ptrs != 0, waypoints));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(device_ptrs != 0, stream);
     tpr::SplineArgs A{};
     A.B = B; A.m = m; A.d = d; A.knots_per_path = knots_per_path; A.bc0 = bc_start; A.bc1 = bc_end;
@@ -670,6 +732,8 @@ int tpr_lp1d_batch(int n, int nrows, const double *v, const double *a, const dou
     if (n < 0 || nrows < 0 || !v || !low || !high || !result || !optval || !optvar || !active)
         return fail(TPR_E_BADARG, "bad lp1d arguments");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(false, nullptr));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(false, stream);
     const size_t nn = (size_t)n, rows = nn * (size_t)nrows;
     const double *dv = S.in(v, nn * 2), *da = S.in(a, rows), *db = S.in(b, rows);
@@ -693,6 +757,8 @@ int tpr_lp2d_batch(int n, int nrows, const double *v, const double *a, const dou
         !optval || !optvar || !active_out)
         return fail(TPR_E_BADARG, "bad lp2d arguments (nrows <= 128)");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(false, nullptr));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(false, stream);
     const size_t nn = (size_t)n, rows = nn * (size_t)nrows;
     const double *dv = S.in(v, nn * 3), *da = S.in(a, rows), *db = S.in(b, rows), *dc = S.in(c, rows);

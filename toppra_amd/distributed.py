@@ -16,15 +16,24 @@ def shard_bounds(total, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def shard_problem(arrays, world_size, rank):
-    """Slice every per-trajectory array (leading dim == B of arrays['coef']) to this rank's shard;
-    shared arrays (1-D grid / breaks) pass through."""
+# Keys of a problem dict that carry one row per trajectory.  Everything else (knots, shared 1-D grid /
+# breaks, scalars) passes through untouched: deciding by "leading dimension happens to equal B" would
+# silently slice a shared array whose length coincides with the batch size.
+PER_TRAJECTORY_KEYS = ("coef", "vlim", "alim", "sd_start", "sd_end", "waypoints", "desired_duration", "sdmin", "sdmax")
+MAYBE_PER_TRAJECTORY_KEYS = ("grid", "breaks")  # per trajectory only when 2-D
+
+
+def shard_problem(arrays, world_size, rank, per_trajectory_keys=PER_TRAJECTORY_KEYS):
+    """Slice the per-trajectory arrays of a problem dict to this rank's contiguous shard; shared arrays
+    pass through.  Returns (shard dict, (lo, hi))."""
     B = arrays["coef"].shape[0]
     lo, hi = shard_bounds(B, world_size, rank)
     out = {}
     for k, v in arrays.items():
-        per_traj = v is not None and hasattr(v, "shape") and len(v.shape) >= 1 and v.shape[0] == B and not (
-            k in ("grid", "breaks") and len(v.shape) == 1)
+        per_traj = v is not None and hasattr(v, "shape") and (
+            (k in per_trajectory_keys and len(v.shape) >= 1) or (k in MAYBE_PER_TRAJECTORY_KEYS and len(v.shape) == 2))
+        if per_traj and v.shape[0] != B:
+            raise ValueError("%s has %d rows, expected one per trajectory (%d)" % (k, v.shape[0], B))
         out[k] = v[lo:hi] if per_traj else v
     return out, (lo, hi)
 
