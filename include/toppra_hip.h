@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define TPR_MAX_DOF 16 /* rows per LP: nC = 2 + 4*d <= 66 */
+#define TPR_MAX_DOF 32      /* generic lane-per-trajectory kernel (rows per LP: nC = 2 + 4*d <= 130)          */
+#define TPR_MAX_DOF_FAST 16 /* rows-across-lanes kernels (auto above 8 dof); 17..32 dof run the generic kernel */
 
 /* tpr_problem.flags */
 #define TPR_HAS_VELOCITY 1      /* JointVelocityConstraint present                             */

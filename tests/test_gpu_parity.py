@@ -81,14 +81,31 @@ def test_empty_batch_and_bad_arguments(gpu):
     assert out["sd2"].shape == (0, 11) and out["status"].shape == (0,)
     from toppra_amd import _capi
     with pytest.raises(_capi.ToppraHipError):  # d > TPR_MAX_DOF
-        big = batch.make_synthetic_batch(2, 17, 10)
+        big = batch.make_synthetic_batch(2, 33, 10)
         batch.solve_batch(big["coef"], big["breaks"], big["grid"], big["vlim"], big["alim"])
     wide = batch.make_synthetic_batch(8, 12, 20)  # d > 8: 16 lanes per trajectory
     assert batch.solve_batch(wide["coef"], wide["breaks"], wide["grid"], wide["vlim"], wide["alim"],
                              variant=2)["status"].shape == (8,)
-    with pytest.raises(_capi.ToppraHipError):  # the fast kernel refuses Collocation when forced
+    with pytest.raises(_capi.ToppraHipError):  # the certified lane kernel refuses Collocation when forced
         batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"],
-                          interpolation=False, variant=2)
+                          interpolation=False, variant=3)
+    with pytest.raises(_capi.ToppraHipError):  # rows across lanes stop at 16 dof when forced
+        big = batch.make_synthetic_batch(2, 20, 10)
+        batch.solve_batch(big["coef"], big["breaks"], big["grid"], big["vlim"], big["alim"], variant=2)
+
+
+@pytest.mark.parametrize("B,d,N", [(200, 17, 40), (130, 24, 60), (70, 32, 30)])
+def test_dof_17_to_32_on_the_generic_kernel(gpu, oracle, B, d, N):
+    """The reference has no dof limit; 17..32 dof run on the generic lane-per-trajectory kernel (auto)."""
+    data = batch.make_synthetic_batch(B, d, N, seed=d)
+    rng = np.random.default_rng(d)
+    sd1 = np.where(rng.random(B) < 0.3, 0.1 * rng.random(B), 0.0)
+    ref = oracle.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], None, sd1)
+    got = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], None, sd1)
+    _compare(got, ref)
+    X = batch.feasible_sets_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    K = batch.controllable_sets_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], sd1, sd1)
+    assert np.array_equal(K, ref["K"], equal_nan=True) and X.shape == K.shape
 
 
 @pytest.mark.parametrize("B,d,N,nway", [(40, 9, 50, 5), (33, 12, 64, 6), (20, 16, 40, 5), (64, 14, 100, 4),
@@ -103,3 +120,32 @@ def test_wide_dof_and_long_splines(gpu, oracle, B, d, N, nway):
         _compare(got, ref)
     strict = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], strict=True)
     _compare(strict, ref)
+
+
+@pytest.mark.parametrize("B,d,N", [(4096, 7, 200), (700, 3, 60), (300, 12, 40)])
+@pytest.mark.parametrize("mode", ["collocation", "acc_only", "vel_only", "collocation_no_vel"])
+def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
+    """Collocation and single-constraint problems run on the rows-across-lanes kernels (the missing
+    acceleration blocks are disabled rows): identical bits to the generic lane kernel, to the full
+    iteration and to the oracle, and the auto selection no longer falls back to the generic kernel."""
+    from oracle.oracle import FLAG_ACC, FLAG_INTERP, FLAG_VEL
+    data = batch.make_synthetic_batch(B, d, N, seed=77 + d)
+    rng = np.random.default_rng(d)
+    sd1 = np.where(rng.random(B) < 0.3, 0.2 * rng.random(B), 0.0)
+    vlim = None if mode in ("acc_only", "collocation_no_vel") else data["vlim"]
+    alim = None if mode == "vel_only" else data["alim"]
+    interp = mode == "acc_only"
+    flags = (FLAG_VEL if vlim is not None else 0) | (FLAG_ACC if alim is not None else 0) | (FLAG_INTERP if interp else 0)
+    args = (data["coef"], data["breaks"], data["grid"], vlim, alim, None, sd1, interp)
+    lane = batch.solve_batch(*args, variant=1)
+    for kw in (dict(variant=2), dict(variant=2, strict=True), dict()):
+        got = batch.solve_batch(*args, **kw)
+        for k in ("K", "sd2", "u", "status"):
+            assert np.array_equal(got[k], lane[k], equal_nan=True), (kw, k)
+    idx = np.arange(0, B, max(1, B // 128))
+    ref = oracle.solve_batch(data["coef"][idx], data["breaks"], data["grid"], None if vlim is None else vlim[idx],
+                             None if alim is None else alim[idx], None, sd1[idx], flags=flags)
+    _compare({k: lane[k][idx] for k in ("K", "sd2", "u", "status")}, ref)
+    X = batch.feasible_sets_batch(data["coef"][:64], data["breaks"], data["grid"], None if vlim is None else vlim[:64],
+                                  None if alim is None else alim[:64], interp)
+    assert X.shape == (64, N + 1, 2) and not np.isnan(X).any()

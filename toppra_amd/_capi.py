@@ -12,7 +12,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOPPRA_HIP_LIB") or os.path.join(HERE, "libtoppra_hip.so")
 
-MAX_DOF = 16
+MAX_DOF = 32       # generic kernel
+MAX_DOF_FAST = 16  # rows-across-lanes kernels
 HAS_VELOCITY = 1
 HAS_ACCELERATION = 2
 ACC_INTERPOLATION = 4

@@ -170,12 +170,16 @@ int launch_group(const tpr::BatchArgs &A, hipStream_t stream) {
     return TPR_E_OK;
 }
 
-// The rows-across-lanes kernels cover the reference's default constraint set (acceleration with
-// Interpolation, velocity optional) for every supported dof: 8 lanes per trajectory up to d = 8,
-// 16 lanes above.
-bool group_supported(const tpr::BatchArgs &A) {
+// The rows-across-lanes kernels cover every constraint set of the path -- acceleration with
+// Interpolation (the reference's default) or Collocation or absent, velocity optional -- for every
+// supported dof: 8 lanes per trajectory up to d = 8, 16 lanes above.  (Missing acceleration blocks are
+// disabled rows in the Interpolation slot layout, see GroupTraj::nblk.)
+bool group_supported(const tpr::BatchArgs &A) { return A.d >= 1 && A.d <= TPR_MAX_DOF_FAST; }
+
+// ... the robust kernel and family 3 are written for the full Interpolation row set
+bool interp_rows(const tpr::BatchArgs &A) {
     const int need = TPR_HAS_ACCELERATION | TPR_ACC_INTERPOLATION;
-    return (A.flags & need) == need && A.d >= 1 && A.d <= TPR_MAX_DOF;
+    return (A.flags & need) == need;
 }
 
 template <int D, int L>
@@ -218,7 +222,7 @@ int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
 // The certified lane kernel (family 3) serves the same constraint set up to 8 dof when sd2, u and
 // status are requested; the strict mode stays with family 2.
 bool cert_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && A.d <= 8 && !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
+    return group_supported(A) && interp_rows(A) && A.d <= 8 && !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
            (A.backward_only || (A.sd2 && A.u && A.status));
 }
 
@@ -340,7 +344,7 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
             return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
         }
         case 2: {
-            if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 2 needs acceleration+interpolation");
+            if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 2: dof out of range");
             // up to 8 dof a trajectory fits 8 lanes; batches that leave most SIMDs idle at that width
             // (<= 8192 trajectories = 1024 waves) run 16 lanes per trajectory: 1.42 -> 1.15 ms at 4096 x 7 x 200
             const bool wide = A.B <= 8192;
@@ -460,7 +464,7 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
     if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
-    if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "TOPPRAsd needs an acceleration constraint with Interpolation");
+    if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "TOPPRAsd: dof out of range");
     const size_t B = (size_t)p->B, N = (size_t)p->N;
     const double *ddes = S.in(desired, B);
     A.sd2 = S.out(r->sd2, B * (N + 1));
@@ -520,7 +524,7 @@ int tpr_robust_solve_batch(const tpr_problem *p, const double *ellipsoid, const 
     P.ru = ellipsoid[0]; P.rx = ellipsoid[1]; P.rc = ellipsoid[2];
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (P.A.B > 0) {
-        if (!P.X && group_supported(P.A) && P.A.d <= 8) {  // rows across lanes; feasible sets / Collocation: lane kernel
+        if (!P.X && group_supported(P.A) && interp_rows(P.A) && P.A.d <= 8) {  // rows across lanes; feasible sets / Collocation: lane kernel
             if (int rc = dispatch_group_robust(P, stream)) return rc;
         } else {
             hipLaunchKernelGGL(tpr::robust_solve_kernel, dim3((P.A.B + 63) / 64), dim3(64), 0, stream, P);
