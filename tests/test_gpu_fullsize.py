@@ -192,3 +192,37 @@ def test_headline_batch_oracle_parity_every_trajectory(gpu, oracle):
         assert len(np.unique(ref["status"])) >= (1 if ci == 0 else 2)
         for k in ("K", "sd2", "u"):
             assert np.array_equal(got[k], ref[k], equal_nan=True), (ci, k)
+
+
+@pytest.mark.parametrize("B,d,N,seed", [(16384, 7, 120, 1), (16384, 4, 100, 2), (8192, 8, 80, 3)])
+def test_near_parallel_rows_are_bit_exact(gpu, B, d, N, seed):
+    """Adversarial for the certificates: one joint is a copy of another, scaled or tilted
+    by 1e-14 .. 1e-6, so that two NON-twin constraint rows are parallel to that accuracy at every gridpoint and
+    either can bind.  This is where the reference's absolute 1e-10 / 1e-8 classifications bite (it declares
+    some of these problems infeasible); the default path must return the full iteration's bits, failures
+    included."""
+    rng = np.random.default_rng(900 + seed)
+    way = rng.standard_normal((B, 5, d))
+    eps = 10.0 ** rng.uniform(-14, -6, size=B)
+    scale = rng.choice([1.0, -1.0, 0.5, 2.0, 3.0], size=B)
+    src, dst = rng.integers(0, d, size=B), rng.integers(0, d, size=B)
+    dst = np.where(dst == src, (src + 1) % d, dst)
+    rows = np.arange(B)
+    way[rows, :, dst] = way[rows, :, src] * (scale * (1 + eps))[:, None]
+    twist = rng.random(B) < 0.5
+    way[rows[twist], :, dst[twist]] += eps[twist, None] * rng.standard_normal((twist.sum(), 5))
+    coef, breaks = batch.spline_coefficients(np.linspace(0, 1, 5), way)
+    vmax = 10 + 20 * rng.random((B, d))
+    amax = 10 + 2 * rng.random((B, d))
+    amax[rows, dst] = amax[rows, src] * np.abs(scale) * (1 + 0.02 * rng.standard_normal(B))
+    vmax[rows, dst] = vmax[rows, src] * np.abs(scale) * (1 + 0.02 * rng.standard_normal(B))
+    vlim = np.ascontiguousarray(np.stack([-vmax, vmax], -1))
+    alim = np.ascontiguousarray(np.stack([-amax, amax], -1))
+    sd1 = np.where(rng.random(B) < 0.3, 0.2 * rng.random(B), 0.0)
+    args = (coef, breaks, np.linspace(0, 1, N + 1), vlim, alim, None, sd1)
+    full = batch.solve_batch(*args, strict=True)
+    assert (full["status"] == 1).sum() >= 1  # the reference itself trips over some of them
+    for variant in (2, 3):
+        fast = batch.solve_batch(*args, variant=variant)
+        for k in ("K", "sd2", "u", "status"):
+            assert np.array_equal(fast[k], full[k], equal_nan=True), (variant, k)
