@@ -92,6 +92,53 @@ def cpu_baseline(data, target_seconds=12.0):
                         "than the reference because it has no Python call overhead -- a stronger baseline)"}}
 
 
+TOL_PROBE = r"""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from toppra_amd import batch as tb
+data = tb.make_synthetic_batch(%(B)d, %(d)d, %(N)d, seed=%(seed)d)
+dev = torch.device("cuda", 0)
+dv = [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]
+out = tb.solve_batch(*dv); torch.cuda.synchronize()
+ms = tb.solve_batch_timed(*dv, out, reps=5)
+np.save(%(tmp)r, out["sd2"].cpu().numpy()); np.save(%(tmp)r + ".status.npy", out["status"].cpu().numpy())
+print(json.dumps({"kernel_ms": ms}))
+"""
+
+
+def tolerance_probe(B, d, N, seed, sd2, status):
+    """The opt-in measurement build (toppra_amd/libtoppra_hip_tol.so, python -m toppra_amd.build --tolerance): same
+    sources with the certified vertices returned as they are, contracted multiply-adds and reciprocal division.
+    Run in a subprocess (one library per process) on the headline batch; deviation against the product's result."""
+    import subprocess
+    import tempfile
+    lib = os.path.join(ROOT, "toppra_amd", "libtoppra_hip_tol.so")
+    if not os.path.exists(lib):
+        return None
+    tmp = os.path.join(tempfile.gettempdir(), "tpr_tol_probe_%d.npy" % os.getpid())
+    env = dict(os.environ, TOPPRA_HIP_LIB=lib)
+    try:
+        outp = subprocess.run([sys.executable, "-c", TOL_PROBE % dict(root=ROOT, B=B, d=d, N=N, seed=seed, tmp=tmp)], env=env,
+                              capture_output=True, text=True, timeout=300)
+        ms = json.loads([l for l in outp.stdout.splitlines() if l.startswith("{")][-1])["kernel_ms"]
+        tol_sd2, tol_status = np.load(tmp), np.load(tmp + ".status.npy")
+    except Exception as exc:  # a failed probe must not take the bench line with it
+        return {"error": repr(exc)[:200]}
+    finally:
+        for f in (tmp, tmp + ".status.npy"):
+            if os.path.exists(f):
+                os.remove(f)
+    return {"kernel_ms": ms, "value_per_gpu": B / ms * 1e3, "unit": "trajectories/s",
+            "max_abs_dsd2_vs_product": float(np.nanmax(np.abs(tol_sd2 - sd2))),
+            "status_identical": bool(np.array_equal(tol_status, status)),
+            "nan_pattern_identical": bool(np.array_equal(np.isnan(tol_sd2), np.isnan(sd2))),
+            "note": "NOT the product: measurement build answering 'what does bit-exactness cost' (the product replicates the "
+                    "reference's last-pivot arithmetic FMA-free with correctly rounded divisions; this build returns the "
+                    "certified vertex itself, with contracted multiply-adds and reciprocal division).  The north star's bar is "
+                    "1e-8 on sd^2; tools/gpu_tolerance_report.py checks every fixture (profiles/r02_tolerance_report.json)"}
+
+
 def baseline_configs(torch, tb, dev):
     """Every configuration of BASELINE.json.configs in one place (rank 0, N=1, outside the timed region):
     C1 latency through the drop-in class, C2 / C3 / C4 kernel times with inputs resident in HBM, and the
@@ -331,6 +378,8 @@ def main():
                         "latencies -- not by HBM: DESIGN.md section 3.5",
             },
         }
+        if not args.no_secondary and world == 1:
+            line["tolerance_build"] = tolerance_probe(B, d, N, 20240924 + rank, out["sd2"].cpu().numpy(), out["status"].cpu().numpy())
         if not args.no_configs and world == 1:
             line["configs"] = baseline_configs(torch, tb, dev)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0's host cores)

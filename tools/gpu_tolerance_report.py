@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""What bit-exactness costs: the opt-in measurement build (python -m toppra_amd.build --tolerance:
+-DTPR_TOLERANCE_MODE, contracted multiply-adds, reciprocal division) against the reference-generated
+fixtures and against the product build on the two full-size batches.  Requirements checked here: status
+codes and NaN patterns identical, max |d sd^2| <= 1e-8 (the north star's bar).
+
+    python tools/gpu_tolerance_report.py            # runs itself twice (product / tolerance library) and compares
+"""
+import json, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+TOL_LIB = os.path.join(ROOT, "toppra_amd", "libtoppra_hip_tol.so")
+
+
+def irregular(B, d, N, nw, seed):
+    from toppra_amd import batch
+    rng = np.random.default_rng(seed)
+    knots = np.concatenate([[0.0], np.sort(rng.random(nw - 2)) * 0.9 + 0.05, [1.0]])
+    way = rng.standard_normal((B, nw, d))
+    still = rng.random((B, d)) < 0.08
+    way = np.where(still[:, None, :], way[:, :1, :], way)
+    coef, breaks = batch.spline_coefficients(knots, way)
+    grid = np.concatenate([[0.0], np.sort(rng.random(N - 1)), [1.0]])
+    grid = 0.6 * grid + 0.4 * np.linspace(0, 1, N + 1)
+    vhi = 5 + 25 * rng.random((B, d)); vlo = -(5 + 25 * rng.random((B, d)))
+    ahi = 5 + 10 * rng.random((B, d)); alo = -(5 + 10 * rng.random((B, d)))
+    sd0 = np.where(rng.random(B) < 0.4, 0.3 * rng.random(B), 0.0)
+    sd1 = np.where(rng.random(B) < 0.4, 0.3 * rng.random(B), 0.0)
+    return (coef, breaks, grid, np.ascontiguousarray(np.stack([vlo, vhi], -1)), np.ascontiguousarray(np.stack([alo, ahi], -1)), sd0, sd1)
+
+
+def worker(out_path):
+    import torch
+    from tests.helpers import batch_fixtures, fixture_problem, golden
+    from toppra_amd import batch
+    res = {}
+    for name in batch_fixtures():
+        fx = golden(name)
+        coef, breaks, grid, vlim, alim, sd0, sd1, interp = fixture_problem(fx)
+        got = batch.solve_batch(coef, breaks, grid, vlim, alim, sd0, sd1, interp, want_sd=True)
+        ok = fx["status"] == 0
+        res[name] = {"status_equal": bool(np.array_equal(got["status"], fx["status"])),
+                     "nan_equal": bool(np.array_equal(np.isnan(got["sd"]), np.isnan(fx["sd"]))),
+                     "max_dsd2": float(np.max(np.abs(got["sd"][ok] ** 2 - fx["sd"][ok] ** 2))) if ok.any() else 0.0,
+                     "max_dK": float(np.nanmax(np.abs(got["K"] - fx["K"]))) if np.isfinite(fx["K"]).any() else 0.0}
+    big = {}
+    data = batch.make_synthetic_batch(65536, 7, 200)
+    cases = {"headline_65536x7x200": (data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], None, None),
+             "irregular_65536x7x200": irregular(65536, 7, 200, 5, 1000)}
+    dev = torch.device("cuda", 0)
+    for name, args in cases.items():
+        out = batch.solve_batch(*args)
+        np.savez(out_path + "." + name + ".npz", **out)
+        dv = [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in args]
+        o = batch.solve_batch(*dv); torch.cuda.synchronize()
+        big[name] = {"kernel_ms": batch.solve_batch_timed(*dv[:5], o, reps=5, sd_start=dv[5], sd_end=dv[6])}
+    json.dump({"fixtures": res, "big": big}, open(out_path, "w"))
+
+
+def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--worker":
+        return worker(sys.argv[2])
+    runs = {}
+    for tag, lib in (("product", None), ("tolerance", TOL_LIB)):
+        env = dict(os.environ)
+        if lib:
+            env["TOPPRA_HIP_LIB"] = lib
+        path = "/tmp/tolrep_%s.json" % tag
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--worker", path], env=env, cwd=ROOT)
+        runs[tag] = json.load(open(path))
+    rep = {"fixtures": {}, "big": {}}
+    worst = 0.0
+    allok = True
+    for name, r in runs["tolerance"]["fixtures"].items():
+        rep["fixtures"][name] = r
+        worst = max(worst, r["max_dsd2"])
+        allok &= r["status_equal"] and r["nan_equal"] and r["max_dsd2"] <= 1e-8
+    for name in runs["product"]["big"]:
+        a = dict(np.load("/tmp/tolrep_product.json.%s.npz" % name)); b = dict(np.load("/tmp/tolrep_tolerance.json.%s.npz" % name))
+        d = {"status_equal": bool(np.array_equal(a["status"], b["status"])),
+             "nan_equal": bool(np.array_equal(np.isnan(a["sd2"]), np.isnan(b["sd2"]))),
+             "max_dsd2": float(np.nanmax(np.abs(a["sd2"] - b["sd2"]))), "max_dK": float(np.nanmax(np.abs(a["K"] - b["K"]))),
+             "max_du": float(np.nanmax(np.abs(a["u"] - b["u"]))),
+             "product_kernel_ms": runs["product"]["big"][name]["kernel_ms"], "tolerance_kernel_ms": runs["tolerance"]["big"][name]["kernel_ms"]}
+        rep["big"][name] = d
+        worst = max(worst, d["max_dsd2"])
+        allok &= d["status_equal"] and d["nan_equal"] and d["max_dsd2"] <= 1e-8
+    rep["summary"] = {"all_requirements_met": bool(allok), "worst_max_dsd2": worst,
+                      "bit_exactness_costs": "%.1f%% of the headline kernel time" % (
+                          100 * (1 - rep["big"]["headline_65536x7x200"]["tolerance_kernel_ms"] / rep["big"]["headline_65536x7x200"]["product_kernel_ms"]))}
+    print(json.dumps(rep, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,20 @@ def stale():
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in deps())
 
 
+def build_tolerance(out=None, verbose=False):
+    """The opt-in measurement build "what does bit-exactness cost" (DESIGN.md): same sources with
+    -DTPR_TOLERANCE_MODE (certified vertices returned as they are, no replication of the reference's
+    last-pivot arithmetic), contracted multiply-adds and reciprocal-based division.  Results agree with the
+    product to ~1e-12, status codes identical; it is NOT the product library and nothing loads it by default."""
+    target = os.path.abspath(out) if out else os.path.join(HERE, "libtoppra_hip_tol.so")
+    flags = [f for f in FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast", "-freciprocal-math", "-DTPR_TOLERANCE_MODE"]
+    cmd = [hipcc()] + flags + ["-o", target] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return target
+
+
 def build(force=False, verbose=False, defines=(), out=None):
     """Build the library.  ``defines`` / ``out`` produce an instrumented copy next to the product one
     (e.g. defines=("TPR_CERT_TIMING", "TPR_CERT_DEV"), used by tools/gpu_cert_phases.py via
@@ -57,6 +71,9 @@ def build(force=False, verbose=False, defines=(), out=None):
 
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if "--tolerance" in args:
+        print(build_tolerance(verbose=True))
+        sys.exit(0)
     defs = [a[2:] for a in args if a.startswith("-D")]
     outs = [a.split("=", 1)[1] for a in args if a.startswith("--out=")]
     print(build(force="--force" in args, verbose=True, defines=defs, out=outs[0] if outs else None))
