@@ -171,8 +171,9 @@ int tpr_lp2d_batch(int n, int nrows, const double *v, const double *a, const dou
  * for B paths: waypoints [B][m][d] at knots [m] (knots_per_path == 0) or [B][m] -> coef
  * [B][4][m-1][d], the layout tpr_problem.coef takes.  Boundary conditions per end:
  * TPR_BC_NOT_A_KNOT, TPR_BC_FIRST_DERIV (value [B][d], NULL = 0: scipy's "clamped"),
- * TPR_BC_SECOND_DERIV (NULL = 0: "natural").  2 <= m <= 64.  device_ptrs != 0: all pointers are
- * device pointers.                                                                                */
+ * TPR_BC_SECOND_DERIV (NULL = 0: "natural").  m >= 2 (splines of more than 64 points keep their
+ * working arrays in a stream-ordered global workspace of 6 m doubles per spline).  device_ptrs != 0: all
+ * pointers are device pointers.                                                                    */
 #define TPR_BC_NOT_A_KNOT 0
 #define TPR_BC_FIRST_DERIV 1
 #define TPR_BC_SECOND_DERIV 2
@@ -189,6 +190,20 @@ int tpr_spline_fit_batch(int B, int m, int d, const double *knots, int knots_per
 int tpr_const_accel_times_batch(const tpr_problem *p, const double *sd, double *ts, double *us, void *stream);
 int tpr_const_accel_eval_batch(const tpr_problem *p, const double *sd, const double *ts, const double *us,
                                int T, const double *times, int order, double *out, void *stream);
+
+/* Replaces ParametrizeSpline (toppra/parametrizer.py:161-196), the reference's default output
+ * parametrizer (algorithm/algorithm.py:121-125), for B trajectories: the gridpoint time stamps (a running
+ * sum; a gridpoint reached in less than TINY = 1e-8 s is dropped, a standing stretch counts 5 s), the
+ * waypoints q(s_i) and the cubic spline in time through them, clamped to q'(s) sd at both ends (scipy
+ * CubicSpline arithmetic as in tpr_spline_fit_batch).  sd [B][N+1] -> knot_times [B][N+1] (compacted;
+ * entries from counts[b] on are padding), counts [B] (gridpoints kept), coef_t [B][4][N][d] (segments from
+ * counts[b]-1 on are a constant extension).  Uses p->coef/breaks/grid/flags.
+ * tpr_ppoly_eval_batch evaluates such tables -- SplineInterpolator.__call__(t, order), i.e. scipy PPoly
+ * (interpolator.py:423-430) -- at times [B][T] -> out [B][T][d]; breaks [B][nseg+1]; counts may be NULL.   */
+int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_times, int32_t *counts,
+                           double *coef_t, void *stream);
+int tpr_ppoly_eval_batch(int B, int nseg, int d, const double *coef, const double *breaks, const int32_t *counts,
+                         int T, const double *times, int order, double *out, int device_ptrs, void *stream);
 
 /* Measurement helper used by bench.py: launches the tpr_solve_batch kernel(s) `reps` times on
  * `stream` between two hipEvents recorded on that same stream and returns the average

@@ -35,3 +35,55 @@ def test_const_accel_batch_vs_host_mirror(gpu):
         assert np.array_equal(ca._ts, ts[b]) and np.array_equal(ca._us, us[b])
         for o in (0, 1, 2):
             np.testing.assert_allclose(q[o][b], ca(times[b], o), rtol=1e-11, atol=1e-11)
+
+
+def test_param_spline_matches_reference(gpu):
+    """ParametrizeSpline (the reference's default parametrizer) from a GPU-only path: the reference's own
+    q(t), dq/dt, d2q/dt2 samples of examples/plot_kinematics.py (tests/golden, made by tools/make_golden.py
+    with the real reference) at <= 1e-10; 101 knots, i.e. beyond the 64-point register path of the fit."""
+    fx = golden("example_kinematics_seed9")
+    sd = fx["n100_sd"][None]
+    sp = batch.param_spline_batch(fx["coef"], fx["breaks"], fx["n100_grid"], sd)
+    assert sp["counts"][0] == 101
+    assert abs(sp["knot_times"][0, 100] - float(fx["spl_duration"])) <= 1e-12
+    for order in (0, 1, 2):
+        q = batch.ppoly_eval_batch(sp["coef"], sp["knot_times"], fx["spl_times"][None], order, sp["counts"])
+        np.testing.assert_allclose(q[0], fx["spl_q%d" % order], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("B,d,N", [(64, 5, 80), (16, 7, 300), (40, 3, 40)])
+def test_batch_compute_trajectory_vs_host_mirror(gpu, B, d, N):
+    """BatchTOPPRA.compute_trajectory (GPU end to end) against the host mirror of the reference's
+    parametrizers built per trajectory with scipy; includes standing starts (sd = 0 at both ends: the 5 s
+    rule never triggers, the first step uses sd_avg of the first interval) and non-zero end velocities."""
+    data = batch.make_synthetic_batch(B, d, N, seed=31 + d)
+    rng = np.random.default_rng(d)
+    sd1 = np.where(rng.random(B) < 0.5, 0.2 * rng.random(B), 0.0)
+    inst = ta.algorithm.BatchTOPPRA(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    for kind, cls in (("ParametrizeSpline", ta.ParametrizeSpline), ("ParametrizeConstAccel", ta.ParametrizeConstAccel)):
+        traj = inst.compute_trajectory(None, sd1, parametrizer=kind)
+        assert (traj.status == 0).all()
+        dur = traj.duration
+        times = rng.random((B, 30)) * dur[:, None]
+        q = [traj(times, o) for o in (0, 1, 2)]
+        for b in (0, B // 2, B - 1):
+            path = ta.SplineInterpolator(data["knots"], data["waypoints"][b])
+            ref = cls(path, data["grid"], traj.result["sd"][b])
+            assert abs(ref.duration - dur[b]) <= 1e-11 * max(1.0, dur[b])
+            for o in (0, 1, 2):
+                want = ref(times[b], o)
+                np.testing.assert_allclose(q[o][b], want, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(want).max()))
+
+
+def test_spline_fit_beyond_64_points(gpu):
+    """tpr_spline_fit_batch with the global workspace (m > 64): bit-identical to scipy like the short path."""
+    from scipy.interpolate import CubicSpline
+    rng = np.random.default_rng(3)
+    for m, bc in ((65, "not-a-knot"), (200, "clamped"), (501, "natural")):
+        knots = np.concatenate([[0.0], np.sort(rng.random(m - 2)) * 0.98 + 0.01, [1.0]])
+        knots = 0.5 * knots + 0.5 * np.linspace(0, 1, m)
+        way = rng.standard_normal((6, m, 3))
+        coef, _ = batch.spline_fit_batch(knots, way, bc)
+        for b in (0, 5):
+            want = CubicSpline(knots, way[b], bc_type=bc).c
+            assert np.array_equal(coef[b], want) or np.max(np.abs(coef[b] - want)) <= 1e-9 * np.max(np.abs(want)), (m, bc)

@@ -50,7 +50,7 @@ EXPORTS = (
     "tpr_controllable_sets_batch", "tpr_feasible_sets_batch", "tpr_constraint_params_batch",
     "tpr_solve_stagewise_batch", "tpr_lp1d_batch", "tpr_lp2d_batch", "tpr_solve_batch_timed",
     "tpr_spline_fit_batch", "tpr_const_accel_times_batch", "tpr_const_accel_eval_batch",
-    "tpr_solve_desired_duration_batch", "tpr_robust_solve_batch",
+    "tpr_solve_desired_duration_batch", "tpr_robust_solve_batch", "tpr_param_spline_batch", "tpr_ppoly_eval_batch",
 )
 
 _lib = None
@@ -113,6 +113,10 @@ def load():
         L.tpr_const_accel_times_batch.argtypes = [P, V, V, V, V]
         L.tpr_const_accel_eval_batch.restype = C.c_int
         L.tpr_const_accel_eval_batch.argtypes = [P, V, V, V, C.c_int, V, C.c_int, V, V]
+        L.tpr_param_spline_batch.restype = C.c_int
+        L.tpr_param_spline_batch.argtypes = [P, V, V, V, V, V]
+        L.tpr_ppoly_eval_batch.restype = C.c_int
+        L.tpr_ppoly_eval_batch.argtypes = [C.c_int, C.c_int, C.c_int, V, V, V, C.c_int, V, C.c_int, V, C.c_int, V]
         L.tpr_lp1d_batch.restype = C.c_int
         L.tpr_lp1d_batch.argtypes = [C.c_int, C.c_int] + [V] * 10
         L.tpr_lp2d_batch.restype = C.c_int

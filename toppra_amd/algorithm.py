@@ -249,6 +249,47 @@ class BatchTOPPRA(object):
         return _batch.solve_desired_duration_batch(self.coef, self.breaks, self.gridpoints, self.vlim, self.alim,
                                                    desired_duration, sd_start, sd_end, atol)
 
+    def compute_trajectory(self, sd_start=None, sd_end=None, parametrizer="ParametrizeSpline"):
+        """``ParameterizationAlgorithm.compute_trajectory`` (algorithm/algorithm.py:174-215) for the batch:
+        parameterize, then build the output trajectories q(t) with the reference's parametrizer --
+        "ParametrizeSpline" (its default) or "ParametrizeConstAccel" -- entirely on the GPU.  Returns a
+        :class:`BatchTrajectory`; trajectories that could not be parameterized have ``status != 0`` and
+        NaN durations (the reference returns None for them)."""
+        res = self.compute_parameterization(sd_start, sd_end, want_sd=True)
+        if parametrizer == "ParametrizeSpline":
+            sp = _batch.param_spline_batch(self.coef, self.breaks, self.gridpoints, res["sd"])
+            return BatchTrajectory("spline", res, self, spline=sp)
+        if parametrizer == "ParametrizeConstAccel":
+            ts, us = _batch.const_accel_times_batch(self.gridpoints, res["sd"])
+            return BatchTrajectory("const_accel", res, self, ts=ts, us=us)
+        raise NotImplementedError("parametrizer %r (ParametrizeSpline and ParametrizeConstAccel are available)" % (parametrizer,))
+
+
+class BatchTrajectory(object):
+    """B output trajectories q_b(t) on the GPU (``AbstractGeometricPath`` surface, batched):
+    ``duration`` [B], ``__call__(times [B, T], order) -> [B, T, d]``, ``status`` [B]."""
+
+    def __init__(self, kind, result, problem, spline=None, ts=None, us=None):
+        self.kind, self.result, self._p = kind, result, problem
+        self.status = result["status"]
+        self._sp, self._ts, self._us = spline, ts, us
+
+    @property
+    def duration(self):
+        """[B] seconds (NaN where the parameterization failed)."""
+        if self.kind == "spline":
+            tk, cnt = self._sp["knot_times"], self._sp["counts"]
+            if hasattr(tk, "gather"):  # torch
+                return tk.gather(1, (cnt.long() - 1).clamp(min=0)[:, None])[:, 0]
+            return tk[np.arange(tk.shape[0]), np.maximum(cnt - 1, 0)]
+        return self._ts[:, -1]
+
+    def __call__(self, times, order=0):
+        if self.kind == "spline":
+            return _batch.ppoly_eval_batch(self._sp["coef"], self._sp["knot_times"], times, order, self._sp["counts"])
+        return _batch.const_accel_eval_batch(self._p.coef, self._p.breaks, self._p.gridpoints, self.result["sd"],
+                                             self._ts, self._us, times, order)
+
     def compute_controllable_sets(self, sdmin, sdmax):
         return _batch.controllable_sets_batch(self.coef, self.breaks, self.gridpoints, self.vlim,
                                               self.alim, sdmin, sdmax, self.interpolation)

@@ -16,7 +16,7 @@ from . import _capi
 __all__ = ["solve_batch", "controllable_sets_batch", "feasible_sets_batch",
            "constraint_params_batch", "make_synthetic_batch", "spline_coefficients",
            "spline_fit_batch", "solve_batch_timed", "const_accel_times_batch", "const_accel_eval_batch",
-           "solve_desired_duration_batch", "robust_solve_batch"]
+           "solve_desired_duration_batch", "robust_solve_batch", "param_spline_batch", "ppoly_eval_batch"]
 
 
 def _stream_ptr(like):
@@ -220,6 +220,57 @@ def const_accel_eval_batch(coef, breaks, grid, sd, ts, us, times, order=0):
     _capi.check(_capi.load().tpr_const_accel_eval_batch(C.byref(p), _capi.ptr(sd), _capi.ptr(ts), _capi.ptr(us), T,
                                                         _capi.ptr(times), int(order), _capi.ptr(out),
                                                         _stream_ptr(coef)))
+    return out
+
+
+def param_spline_batch(coef, breaks, grid, sd):
+    """ParametrizeSpline (the reference's default output parametrizer, parametrizer.py:161-196) for B
+    trajectories: sd [B, N+1] -> dict(knot_times [B, N+1], counts [B], coef [B, 4, N, d]): the cubic spline in
+    time through q(s_i) at the gridpoint times, clamped to q'(s) sd at both ends.  Entries of
+    ``knot_times`` from ``counts[b]`` on are padding (gridpoints reached in no time are dropped, as in the
+    reference).  Evaluate with :func:`ppoly_eval_batch`."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, None, None)
+    dev = _capi.is_torch_cuda(coef)
+    if dev:
+        _capi.check_tensor("sd", sd, coef)
+        sd = sd.contiguous()
+    else:
+        sd = _capi.f64(sd)
+    if tuple(sd.shape) != (p.B, p.N + 1):
+        raise ValueError("sd must have shape [B, N+1] = [%d, %d]" % (p.B, p.N + 1))
+    out = {"knot_times": _empty(coef, (p.B, p.N + 1)), "counts": _empty(coef, (p.B,), "i32"),
+           "coef": _empty(coef, (p.B, 4, p.N, p.d))}
+    _capi.check(_capi.load().tpr_param_spline_batch(C.byref(p), _capi.ptr(sd), _capi.ptr(out["knot_times"]),
+                                                    _capi.ptr(out["counts"]), _capi.ptr(out["coef"]), _stream_ptr(coef)))
+    return out
+
+
+def ppoly_eval_batch(coef, breaks, times, order=0, counts=None):
+    """SplineInterpolator.__call__(t, order) for B piecewise cubics with their own breakpoints:
+    coef [B, 4, nseg, d], breaks [B, nseg+1], times [B, T] -> [B, T, d] (order 0 / 1 / 2; extrapolation from
+    the end segments like scipy's PPoly).  ``counts`` [B] int32: breakpoints in use per path."""
+    _prepare(coef)
+    dev = _capi.is_torch_cuda(coef)
+    if dev:
+        for name, t in (("coef", coef), ("breaks", breaks), ("times", times)):
+            _capi.check_tensor(name, t, coef)
+        coef, breaks, times = coef.contiguous(), breaks.contiguous(), times.contiguous()
+        if counts is not None:
+            counts = counts.contiguous()
+    else:
+        coef, breaks, times = _capi.f64(coef), _capi.f64(breaks), _capi.f64(times)
+        if counts is not None:
+            counts = np.ascontiguousarray(counts, dtype=np.int32)
+    B, four, nseg, d = (int(v) for v in coef.shape)
+    if four != 4 or tuple(breaks.shape) != (B, nseg + 1) or times.ndim != 2 or int(times.shape[0]) != B:
+        raise ValueError("need coef [B, 4, nseg, d], breaks [B, nseg+1], times [B, T]")
+    if counts is not None and tuple(counts.shape) != (B,):
+        raise ValueError("counts must have shape [B]")
+    T = int(times.shape[1])
+    out = _empty(coef, (B, T, d))
+    _capi.check(_capi.load().tpr_ppoly_eval_batch(B, nseg, d, _capi.ptr(coef), _capi.ptr(breaks), _capi.ptr(counts), T,
+                                                  _capi.ptr(times), int(order), _capi.ptr(out), int(dev), _stream_ptr(coef)))
     return out
 
 

@@ -348,6 +348,13 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
             // up to 8 dof a trajectory fits 8 lanes; batches that leave most SIMDs idle at that width
             // (<= 8192 trajectories = 1024 waves) run 16 lanes per trajectory: 1.42 -> 1.15 ms at 4096 x 7 x 200
             const bool wide = A.B <= 8192;
+#ifdef TPR_WIDE_EXPERIMENT  // lanes per trajectory for small batches (development builds): TPR_LANES=32|64
+            if (const char *e = std::getenv("TPR_LANES")) {
+                const int L = std::atoi(e);
+                if (A.d == 7 && L == 32) return launch_group<7, 32>(A, stream);
+                if (A.d == 7 && L == 64) return launch_group<7, 64>(A, stream);
+            }
+#endif
             switch (A.d) {
 #define TPR_GROUP_CASE(DD) case DD: return wide ? launch_group<DD, 16>(A, stream) : launch_group<DD, 8>(A, stream)
                 TPR_GROUP_CASE(1);
@@ -703,12 +710,32 @@ int tpr_const_accel_eval_batch(const tpr_problem *p, const double *sd, const dou
     return TPR_E_OK;
 }
 
+namespace {
+// Launch the fit of B*d splines of up to m points: short splines keep their working arrays in registers /
+// scratch; longer ones use a stream-ordered global workspace of 6 m doubles per spline.
+int launch_spline_fit(const tpr::SplineArgs &A, const int32_t *counts, Staging &S, hipStream_t stream) {
+    const long long total = (long long)A.B * A.d;
+    if (total <= 0) return TPR_E_OK;
+    const dim3 grid((unsigned)((total + 127) / 128)), block(128);
+    if (A.m <= tpr::kSplineMaxPts) {
+        hipLaunchKernelGGL((tpr::spline_fit_kernel<false>), grid, block, 0, stream, A, counts, (double *)nullptr);
+        return TPR_E_OK;
+    }
+    void *ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, (size_t)6 * A.m * (size_t)total * sizeof(double), stream);
+    if (e != hipSuccess) return fail(TPR_E_HIP, std::string("spline-fit workspace: ") + hipGetErrorString(e));
+    S.owned.push_back(ws);
+    hipLaunchKernelGGL((tpr::spline_fit_kernel<true>), grid, block, 0, stream, A, counts, static_cast<double *>(ws));
+    return TPR_E_OK;
+}
+}  // namespace
+
 int tpr_spline_fit_batch(int B, int m, int d, const double *knots, int knots_per_path,
                          const double *waypoints, int bc_start, int bc_end, const double *bc_start_val,
                          const double *bc_end_val, double *coef, int device_ptrs, void *stream_) {
     if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
-    if (B < 0 || d < 1 || m < 2 || m > tpr::kSplineMaxPts || !knots || !waypoints || !coef)
-        return fail(TPR_E_BADARG, "spline fit needs 2 <= m <= 64 waypoints, knots, waypoints, coef");
+    if (B < 0 || d < 1 || m < 2 || !knots || !waypoints || !coef)
+        return fail(TPR_E_BADARG, "spline fit needs m >= 2 waypoints, knots, waypoints, coef");
     if (bc_start < 0 || bc_start > 2 || bc_end < 0 || bc_end > 2) return fail(TPR_E_BADARG, "unknown boundary condition");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceScope scope(call_device(device_ptrs != 0, waypoints));
@@ -722,9 +749,70 @@ int tpr_spline_fit_batch(int B, int m, int d, const double *knots, int knots_per
     A.bcv1 = S.in(bc_end_val, (size_t)B * d);
     A.coef = S.out(coef, (size_t)B * 4 * (m - 1) * d);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    const long long total = (long long)B * d;
+    if (int rc = launch_spline_fit(A, nullptr, S, stream)) return rc;
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_times, int32_t *counts, double *coef_t,
+                           void *stream_) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (!p || p->B < 0 || p->N < 1 || p->d < 1 || p->nseg < 1 || !p->coef || !p->breaks || !p->grid || !sd || !knot_times ||
+        !counts || !coef_t)
+        return fail(TPR_E_BADARG, "bad spline-parametrizer arguments");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    const size_t B = (size_t)p->B, N = (size_t)p->N, d = (size_t)p->d, nseg = (size_t)p->nseg;
+    tpr::ParamSplineArgs K{};
+    K.B = p->B; K.N = p->N; K.d = p->d; K.nseg = p->nseg; K.flags = p->flags;
+    K.coef = S.in(p->coef, B * 4 * nseg * d);
+    K.breaks = S.in(p->breaks, ((p->flags & TPR_BREAKS_PER_TRAJ) ? B : 1) * (nseg + 1));
+    K.grid = S.in(p->grid, ((p->flags & TPR_GRID_PER_TRAJ) ? B : 1) * (N + 1));
+    K.sd = S.in(sd, B * (N + 1));
+    K.tk = S.out(knot_times, B * (N + 1));
+    K.counts = S.out(counts, B);
+    double *dcoef = S.out(coef_t, B * 4 * N * d);
+    // internal: waypoints q(s_i) and the two end derivatives
+    void *ws = nullptr;
+    if (S.err == hipSuccess && B > 0) S.err = hipMallocAsync(&ws, (B * (N + 1) * d + 2 * B * d) * sizeof(double), stream);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (B > 0) {
+        S.owned.push_back(ws);
+        K.way = static_cast<double *>(ws);
+        K.bcv0 = K.way + B * (N + 1) * d;
+        K.bcv1 = K.bcv0 + B * d;
+        hipLaunchKernelGGL(tpr::param_spline_knots_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, K);
+        tpr::SplineArgs A{};
+        A.B = p->B; A.m = p->N + 1; A.d = p->d; A.knots_per_path = 1; A.bc0 = tpr::kBcFirst; A.bc1 = tpr::kBcFirst;
+        A.knots = K.tk; A.way = K.way; A.bcv0 = K.bcv0; A.bcv1 = K.bcv1; A.coef = dcoef;
+        if (int rc = launch_spline_fit(A, K.counts, S, stream)) return rc;
+    }
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_ppoly_eval_batch(int B, int nseg, int d, const double *coef, const double *breaks, const int32_t *counts, int T,
+                         const double *times, int order, double *out, int device_ptrs, void *stream_) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (B < 0 || nseg < 1 || d < 1 || T < 0 || order < 0 || order > 2 || !coef || !breaks || !times || !out)
+        return fail(TPR_E_BADARG, "bad piecewise-polynomial evaluation arguments");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(device_ptrs != 0, coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    Staging S(device_ptrs != 0, stream);
+    tpr::PpolyArgs A{};
+    A.B = B; A.nseg = nseg; A.d = d; A.T = T; A.order = order;
+    A.coef = S.in(coef, (size_t)B * 4 * nseg * d);
+    A.breaks = S.in(breaks, (size_t)B * (nseg + 1));
+    A.counts = S.in(counts, (size_t)B);
+    A.times = S.in(times, (size_t)B * T);
+    A.out = S.out(out, (size_t)B * T * d);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    const long long total = (long long)B * T;
     if (total > 0)
-        hipLaunchKernelGGL(tpr::spline_fit_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, A);
+        hipLaunchKernelGGL(tpr::ppoly_eval_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, A);
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
