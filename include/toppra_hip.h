@@ -134,6 +134,14 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
  * X [B][N+1][2].                                                                                 */
 int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream);
 
+/* Replaces ReachabilityAlgorithm.compute_reachable_sets(sdmin, sdmax) (reachability_algorithm.py:378-431):
+ * the feasible sets, then the forward propagation of the reachable velocities from [sdmin^2, sdmax^2] --
+ * including the reference's use of the PREVIOUS interval's delta in the objective (:384) and the warm-start
+ * state shared with the feasible-set pass.  sdmin/sdmax [B]; L [B][N+1][2] (zeros after a NaN stage, as in
+ * the reference); X [B][N+1][2] feasible sets (may be NULL).                                          */
+int tpr_reachable_sets_batch(const tpr_problem *p, const double *sdmin, const double *sdmax, double *L, double *X,
+                             void *stream);
+
 /* Replaces Constraint.compute_constraint_params + the dense row build of seidelWrapper.__init__
  * (linear_joint_velocity.py:43-53, linear_joint_acceleration.py:63-104,
  * linear_constraint.py:164-190, cy_seidel_solverwrapper.pyx:474-520):

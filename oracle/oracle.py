@@ -62,6 +62,8 @@ def lib():
         L.orc_compute_controllable_sets.argtypes = [C.c_void_p, C.c_double, C.c_double, dp]
         L.orc_compute_feasible_sets.restype = None
         L.orc_compute_feasible_sets.argtypes = [C.c_void_p, dp]
+        L.orc_compute_reachable_sets.restype = None
+        L.orc_compute_reachable_sets.argtypes = [C.c_void_p, C.c_double, C.c_double, dp, dp]
         L.orc_compute_parameterization.restype = C.c_int
         L.orc_compute_parameterization.argtypes = [C.c_void_p, C.c_double, C.c_double, dp, dp, dp, dp]
         L.orc_solve_batch.restype = C.c_int
@@ -209,6 +211,13 @@ class Wrapper:
         X = np.zeros((self.N + 1, 2))
         lib().orc_compute_feasible_sets(self._h, _dp(X))
         return X
+
+    def compute_reachable_sets(self, sdmin, sdmax):
+        """Returns (L[N+1,2], X[N+1,2])."""
+        L = np.zeros((self.N + 1, 2))
+        X = np.zeros((self.N + 1, 2))
+        lib().orc_compute_reachable_sets(self._h, float(sdmin), float(sdmax), _dp(L), _dp(X))
+        return L, X
 
     def compute_parameterization(self, sd_start, sd_end):
         """Returns (status, sdd[N], sd[N+1], xs[N+1], K[N+1,2])."""

@@ -190,3 +190,16 @@ def test_K_is_optional_and_inputs_are_validated(gpu):
         batch.solve_batch(dv[0], dv[1], dv[2], dv[3].cpu(), dv[4])           # host tensor mixed in
     with pytest.raises(ValueError):
         batch.solve_batch(*dv, sd_end=torch.zeros(7, dtype=torch.float64, device=dev))
+
+
+def test_compute_reachable_sets_drop_in(gpu):
+    """ReachabilityAlgorithm.compute_reachable_sets on the drop-in class (reference fixture trajectory 1)."""
+    fx = golden("reach_d5_N60")
+    b = 1
+    path = ta.SplineInterpolator(np.linspace(0, 1, 5), None, coef=fx["coef"][b], breaks=fx["breaks"]) if False else None
+    from toppra_amd import batch as tb
+    L = tb.reachable_sets_batch(fx["coef"][b:b + 1], fx["breaks"], fx["grid"], fx["vlim"][b:b + 1], fx["alim"][b:b + 1],
+                                fx["sdmin"][b:b + 1], fx["sdmax"][b:b + 1])
+    assert_same(L[0], fx["L"][b], "L")
+    inst = ta.algorithm.BatchTOPPRA(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"])
+    assert_same(inst.compute_reachable_sets(fx["sdmin"], fx["sdmax"]), fx["L"], "batch L")

@@ -132,3 +132,22 @@ def test_random_lps_match_reference(gpu):
     assert_same(val[ok], fx["optval1"][ok], "optval1")
     assert_same(var[ok], fx["optvar1"][ok], "optvar1")
     assert np.array_equal(act[ok], fx["active1"][ok])
+
+
+@pytest.mark.parametrize("name", ["reach_d5_N60", "reach_d3_N40_collocation"])
+def test_reachable_sets_fixture(gpu, oracle, name):
+    """compute_reachable_sets against the real reference's outputs (tools/make_golden.py: non-uniform grid,
+    sdmin == sdmax and sdmin < sdmax starts, infeasible starts) and against the oracle; the single-trajectory
+    drop-in method too."""
+    import toppra_amd as ta
+    fx = golden(name)
+    interp = bool(int(fx["interpolation"]))
+    L, X = batch.reachable_sets_batch(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"], fx["sdmin"], fx["sdmax"],
+                                      interp, want_X=True)
+    assert np.isnan(fx["L"]).any()
+    assert_same(L, fx["L"], "L")
+    assert_same(X, fx["X"], "X")
+    flags = oracle.FLAG_VEL | oracle.FLAG_ACC | (oracle.FLAG_INTERP if interp else 0)
+    for b in (0, 3):
+        w = oracle.Wrapper(fx["coef"][b], fx["breaks"], fx["grid"], fx["vlim"][b], fx["alim"][b], flags=flags)
+        assert_same(w.compute_reachable_sets(float(fx["sdmin"][b]), float(fx["sdmax"][b]))[0], L[b], "oracle L")

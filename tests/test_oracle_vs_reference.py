@@ -116,3 +116,27 @@ def test_velocity_bound_is_fp32(reference, oracle):
     # and it is NOT what fp64 arithmetic would give
     assert np.any(got[:, 1] != np.array([np.min(np.where(q > 0, vlim[:, 1] / q, vlim[:, 0] / q)) ** 2
                                          for q in np.where(qs == 0, 1e-30, qs)]))
+
+
+@pytest.mark.parametrize("d,N,scheme,sds", [(7, 100, 1, (0.0, 0.0)), (5, 60, 1, (0.0, 0.3)), (3, 40, 0, (0.1, 0.4)), (6, 80, 1, (0.5, 0.5))])
+def test_reachable_sets_match_reference(reference, oracle, d, N, scheme, sds):
+    """compute_reachable_sets (reachability_algorithm.py:378-431) incl. its deltas[i-1] objective and the
+    warm-start state carried over from the feasible-set pass it runs first."""
+    import toppra.algorithm as algo
+    import toppra.constraint as constraint
+    rng = np.random.default_rng(77 * d + N)
+    knots = np.linspace(0, 1, 5)
+    grid = np.concatenate([[0.0], np.sort(rng.random(N - 1)), [1.0]])
+    grid = 0.5 * grid + 0.5 * np.linspace(0, 1, N + 1)   # non-uniform: deltas[i-1] != deltas[i]
+    for _ in range(8):
+        way, vl, al = _problem(rng, d)
+        path = reference.SplineInterpolator(knots, way)
+        cons = [constraint.JointVelocityConstraint(vl),
+                constraint.JointAccelerationConstraint(al, discretization_scheme=scheme)]
+        inst = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        L = inst.compute_reachable_sets(*sds)
+        flags = oracle.FLAG_VEL | oracle.FLAG_ACC | (oracle.FLAG_INTERP if scheme else 0)
+        w = oracle.Wrapper(path.cspl.c, path.cspl.x, grid, vl, al, flags=flags)
+        oL, oX = w.compute_reachable_sets(*sds)
+        assert_same(oL, L, "L")
+        assert_same(oX, inst.problem_data.X, "X")

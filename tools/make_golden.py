@@ -298,8 +298,42 @@ def lp_fixture():
     print("random_lps: feasible 2-D", int(np.sum(out["result"])), "of", n, "; 1-D", int(np.sum(out["result1"])))
 
 
+def reachable_fixture(name="reach_d5_N60", B=24, d=5, N=60, seed=41, scheme=1):
+    """compute_reachable_sets (reachability_algorithm.py:409-431) on a non-uniform grid, per-trajectory
+    [sdmin, sdmax] incl. sdmin == sdmax (the 1-D LP path of the first stage) and starts too fast to be feasible."""
+    rng = np.random.default_rng(seed)
+    knots = np.linspace(0, 1, 5)
+    grid = np.concatenate([[0.0], np.sort(rng.random(N - 1)), [1.0]])
+    grid = 0.5 * grid + 0.5 * np.linspace(0, 1, N + 1)
+    recs = {k: [] for k in ("coef", "vlim", "alim", "sdmin", "sdmax", "L", "X")}
+    for b in range(B):
+        way = rng.standard_normal((5, d))
+        vmax = 10 + 20 * rng.random(d); amax = 10 + 2 * rng.random(d)
+        vl, al = np.stack([-vmax, vmax], 1), np.stack([-amax, amax], 1)
+        mode = b % 4
+        sdmin = 0.0 if mode in (0, 1) else 0.3 * rng.random()
+        sdmax = sdmin if mode in (0, 2) else sdmin + 0.5 * rng.random()
+        if b % 11 == 10:
+            sdmin = sdmax = 50.0   # far above the velocity limit: the first stage is infeasible
+        path = ta.SplineInterpolator(knots, way)
+        cons = [constraint.JointVelocityConstraint(vl), constraint.JointAccelerationConstraint(al, discretization_scheme=scheme)]
+        inst = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        L = inst.compute_reachable_sets(sdmin, sdmax)
+        for k, v in (("coef", np.asarray(path.cspl.c)), ("vlim", vl), ("alim", al), ("sdmin", sdmin), ("sdmax", sdmax),
+                     ("L", L), ("X", inst.problem_data.X)):
+            recs[k].append(v)
+    out = {k: np.array(v) for k, v in recs.items()}
+    out.update(breaks=np.asarray(path.cspl.x), grid=grid, interpolation=np.array(scheme))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, ": trajectories with a NaN stage", int(np.isnan(out["L"]).any(axis=(1, 2)).sum()), "of", B)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--reachable-only" in sys.argv:
+        reachable_fixture()
+        reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)
+        raise SystemExit(0)
     example_fixture()
     cpp_fixture()
     hard_fixture()
@@ -319,3 +353,5 @@ if __name__ == "__main__":
     batch_fixture("batch_d9_N60", 8, 9, 60, seed=13, feasible=True)
     batch_fixture("batch_d14_N40_boundary", 6, 14, 40, seed=14, sd_mode="random")
     batch_fixture("batch_d16_N30", 4, 16, 30, seed=15)
+    reachable_fixture()
+    reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)

@@ -51,6 +51,7 @@ EXPORTS = (
     "tpr_solve_stagewise_batch", "tpr_lp1d_batch", "tpr_lp2d_batch", "tpr_solve_batch_timed",
     "tpr_spline_fit_batch", "tpr_const_accel_times_batch", "tpr_const_accel_eval_batch",
     "tpr_solve_desired_duration_batch", "tpr_robust_solve_batch", "tpr_param_spline_batch", "tpr_ppoly_eval_batch",
+    "tpr_reachable_sets_batch",
 )
 
 _lib = None
@@ -100,6 +101,8 @@ def load():
         L.tpr_solve_batch_timed.argtypes = [P, R, V, C.c_int, C.POINTER(C.c_float)]
         L.tpr_controllable_sets_batch.restype = C.c_int
         L.tpr_controllable_sets_batch.argtypes = [P, V, V, V, V]
+        L.tpr_reachable_sets_batch.restype = C.c_int
+        L.tpr_reachable_sets_batch.argtypes = [P, V, V, V, V, V]
         L.tpr_feasible_sets_batch.restype = C.c_int
         L.tpr_feasible_sets_batch.argtypes = [P, V, V]
         L.tpr_constraint_params_batch.restype = C.c_int

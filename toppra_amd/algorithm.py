@@ -134,6 +134,19 @@ class ReachabilityAlgorithm(ParameterizationAlgorithm):
         self._problem_data.X = X
         return X
 
+    def compute_reachable_sets(self, sdmin, sdmax):
+        """L[N+1, 2]: squared velocities reachable from [sdmin^2, sdmax^2] at the start
+        (reachability_algorithm.py:409-431; computes and stores the feasible sets on the way, like the
+        reference).  A NaN row marks the stage that failed; the rows after it stay zero."""
+        assert sdmin <= sdmax and 0 <= sdmin
+        L, X = self.solver_wrapper.reachable_sets(sdmin, sdmax)
+        self._problem_data.X = np.array(X)
+        L = np.array(L)
+        if np.isnan(L).any():
+            i = int(np.argmax(np.isnan(L).any(axis=1)))
+            logger.warning("L[{:d}]={:}. Path not parametrizable.".format(i, L[i]))
+        return L
+
     def compute_controllable_sets(self, sdmin, sdmax):
         """K[N+1, 2]: controllable squared velocities; a NaN row marks the stage that failed and
         the rows above it stay zero, as in the reference."""
@@ -265,6 +278,24 @@ class BatchTOPPRA(object):
         raise NotImplementedError("parametrizer %r (ParametrizeSpline and ParametrizeConstAccel are available)" % (parametrizer,))
 
 
+    def compute_controllable_sets(self, sdmin, sdmax):
+        return _batch.controllable_sets_batch(self.coef, self.breaks, self.gridpoints, self.vlim,
+                                              self.alim, sdmin, sdmax, self.interpolation)
+
+    def compute_feasible_sets(self):
+        return _batch.feasible_sets_batch(self.coef, self.breaks, self.gridpoints, self.vlim,
+                                          self.alim, self.interpolation)
+
+    def compute_reachable_sets(self, sdmin, sdmax):
+        """L[B, N+1, 2] (reachability_algorithm.py:409-431 per trajectory)."""
+        return _batch.reachable_sets_batch(self.coef, self.breaks, self.gridpoints, self.vlim, self.alim, sdmin, sdmax,
+                                           self.interpolation)
+
+    @staticmethod
+    def return_codes(status):
+        return [_STATUS_TO_CODE[int(s)] for s in np.asarray(status)]
+
+
 class BatchTrajectory(object):
     """B output trajectories q_b(t) on the GPU (``AbstractGeometricPath`` surface, batched):
     ``duration`` [B], ``__call__(times [B, T], order) -> [B, T, d]``, ``status`` [B]."""
@@ -289,15 +320,3 @@ class BatchTrajectory(object):
             return _batch.ppoly_eval_batch(self._sp["coef"], self._sp["knot_times"], times, order, self._sp["counts"])
         return _batch.const_accel_eval_batch(self._p.coef, self._p.breaks, self._p.gridpoints, self.result["sd"],
                                              self._ts, self._us, times, order)
-
-    def compute_controllable_sets(self, sdmin, sdmax):
-        return _batch.controllable_sets_batch(self.coef, self.breaks, self.gridpoints, self.vlim,
-                                              self.alim, sdmin, sdmax, self.interpolation)
-
-    def compute_feasible_sets(self):
-        return _batch.feasible_sets_batch(self.coef, self.breaks, self.gridpoints, self.vlim,
-                                          self.alim, self.interpolation)
-
-    @staticmethod
-    def return_codes(status):
-        return [_STATUS_TO_CODE[int(s)] for s in np.asarray(status)]

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _capi
 
-__all__ = ["solve_batch", "controllable_sets_batch", "feasible_sets_batch",
+__all__ = ["solve_batch", "controllable_sets_batch", "feasible_sets_batch", "reachable_sets_batch",
            "constraint_params_batch", "make_synthetic_batch", "spline_coefficients",
            "spline_fit_batch", "solve_batch_timed", "const_accel_times_batch", "const_accel_eval_batch",
            "solve_desired_duration_batch", "robust_solve_batch", "param_spline_batch", "ppoly_eval_batch"]
@@ -146,6 +146,20 @@ def controllable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interp
     _capi.check(_capi.load().tpr_controllable_sets_batch(C.byref(p), _capi.ptr(sdmin), _capi.ptr(sdmax),
                                                          _capi.ptr(K), _stream_ptr(coef)))
     return K
+
+
+def reachable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpolation=True, want_X=False):
+    """compute_reachable_sets(sdmin, sdmax) for B trajectories -> L[B,N+1,2] (and the feasible sets
+    X[B,N+1,2] it computes on the way with ``want_X``)."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation)
+    sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, coef)
+    sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, coef)
+    L = _empty(coef, (p.B, p.N + 1, 2))
+    X = _empty(coef, (p.B, p.N + 1, 2)) if want_X else None
+    _capi.check(_capi.load().tpr_reachable_sets_batch(C.byref(p), _capi.ptr(sdmin), _capi.ptr(sdmax), _capi.ptr(L),
+                                                      _capi.ptr(X), _stream_ptr(coef)))
+    return (L, X) if want_X else L
 
 
 def feasible_sets_batch(coef, breaks, grid, vlim, alim, interpolation=True):

@@ -597,6 +597,32 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
     return TPR_E_OK;
 }
 
+int tpr_reachable_sets_batch(const tpr_problem *p, const double *sdmin, const double *sdmax, double *L, double *X,
+                             void *stream_) {
+    if (int rc = check_problem(p)) return rc;
+    if (!sdmin || !sdmax || !L) return fail(TPR_E_BADARG, "sdmin/sdmax/L are required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::BatchArgs A = stage_problem(p, S);
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    const double *dmin = S.in(sdmin, B), *dmax = S.in(sdmax, B);
+    double *dL = S.out(L, B * (N + 1) * 2);
+    double *dX = S.out(X, B * (N + 1) * 2);
+    if (!dX && B > 0) {  // the feasible sets are an intermediate when the caller does not ask for them
+        void *ws = nullptr;
+        if (S.err == hipSuccess) S.err = hipMallocAsync(&ws, B * (N + 1) * 2 * sizeof(double), stream);
+        if (S.err == hipSuccess) S.owned.push_back(ws);
+        dX = static_cast<double *>(ws);
+    }
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (A.B > 0)
+        hipLaunchKernelGGL(tpr::lane_reachable_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dmin, dmax, dL, dX);
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
 int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
     if (int rc = check_problem(p)) return rc;
     if (!X) return fail(TPR_E_BADARG, "X is required");

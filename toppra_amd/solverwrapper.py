@@ -122,6 +122,11 @@ class hipSeidelWrapper(SolverWrapper):
     def feasible_sets(self):
         return batch.feasible_sets_batch(*self._args(), self._interp)[0]
 
+    def reachable_sets(self, sdmin, sdmax):
+        L, X = batch.reachable_sets_batch(*self._args(), np.array([sdmin], dtype=np.float64),
+                                          np.array([sdmax], dtype=np.float64), self._interp, want_X=True)
+        return L[0], X[0]
+
     def parameterization(self, sd_start, sd_end):
         out = batch.solve_batch(*self._args(), np.array([sd_start], dtype=np.float64),
                                 np.array([sd_end], dtype=np.float64), self._interp, want_sd=True)
