@@ -192,14 +192,22 @@ def test_K_is_optional_and_inputs_are_validated(gpu):
         batch.solve_batch(*dv, sd_end=torch.zeros(7, dtype=torch.float64, device=dev))
 
 
-def test_compute_reachable_sets_drop_in(gpu):
-    """ReachabilityAlgorithm.compute_reachable_sets on the drop-in class (reference fixture trajectory 1)."""
+def test_compute_reachable_sets_drop_in(gpu, oracle):
+    """ReachabilityAlgorithm.compute_reachable_sets on the drop-in class vs the oracle (itself pinned to the
+    reference live and through tests/golden/reach_*.npz), and the batch method on the reference fixture."""
+    rng = np.random.default_rng(12)
+    way = rng.standard_normal((5, 4))
+    path = ta.SplineInterpolator(np.linspace(0, 1, 5), way)
+    vl = np.stack([-np.full(4, 15.0), np.full(4, 15.0)], 1)
+    al = np.stack([-np.full(4, 11.0), np.full(4, 11.0)], 1)
+    grid = np.linspace(0, 1, 51)
+    inst = ta.algorithm.TOPPRA([ta.constraint.JointVelocityConstraint(vl), ta.constraint.JointAccelerationConstraint(al)],
+                               path, gridpoints=grid)
+    L = inst.compute_reachable_sets(0.0, 0.2)
+    w = oracle.Wrapper(path.cspl.c, path.cspl.x, grid, vl, al)
+    wantL, wantX = w.compute_reachable_sets(0.0, 0.2)
+    assert_same(L, wantL, "L")
+    assert_same(inst.problem_data.X, wantX, "X")
     fx = golden("reach_d5_N60")
-    b = 1
-    path = ta.SplineInterpolator(np.linspace(0, 1, 5), None, coef=fx["coef"][b], breaks=fx["breaks"]) if False else None
-    from toppra_amd import batch as tb
-    L = tb.reachable_sets_batch(fx["coef"][b:b + 1], fx["breaks"], fx["grid"], fx["vlim"][b:b + 1], fx["alim"][b:b + 1],
-                                fx["sdmin"][b:b + 1], fx["sdmax"][b:b + 1])
-    assert_same(L[0], fx["L"][b], "L")
-    inst = ta.algorithm.BatchTOPPRA(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"])
-    assert_same(inst.compute_reachable_sets(fx["sdmin"], fx["sdmax"]), fx["L"], "batch L")
+    binst = ta.algorithm.BatchTOPPRA(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"])
+    assert_same(binst.compute_reachable_sets(fx["sdmin"], fx["sdmax"]), fx["L"], "batch L")
