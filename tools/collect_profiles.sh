@@ -8,6 +8,9 @@ cp gpurun_out/pmc_summary.txt profiles/${R}_rocprofv3_pmc_summary.txt
 cp gpurun_out/prof_stats/run_kernel_stats.csv profiles/${R}_rocprofv3_kernel_stats.csv
 cp gpurun_out/measure.json profiles/${R}_secondary_measurements.json
 cp gpurun_out/stress.log profiles/${R}_shortcut_vs_full_seidel_stress.log
+[ -f gpurun_out/near_parallel.log ] && cp gpurun_out/near_parallel.log profiles/${R}_near_parallel_rows_stress.log
+[ -f gpurun_out/tolerance_report.json ] && cp gpurun_out/tolerance_report.json profiles/${R}_tolerance_report.json
+[ -f gpurun_out/walk_fail.log ] && cp gpurun_out/walk_fail.log profiles/${R}_walk_give_ups_and_regime_transitions.log
 [ -f gpurun_out/hitrate.log ] && cp gpurun_out/hitrate.log profiles/${R}_shortcut_hit_rate.log
 [ -f gpurun_out/phases.log ] && cp gpurun_out/phases.log profiles/${R}_family3_cycle_breakdown.log
 ls -la profiles | tail -12

@@ -11,16 +11,19 @@ timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -5 | tee gpurun_out/pyt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 timeout 600 python tools/gpu_measure.py 2>/dev/null > gpurun_out/measure.json; tail -5 gpurun_out/measure.json
 rm -rf gpurun_out/prof_*
-bash tools/gpu_profile.sh "--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --kernel-reps 2" all > gpurun_out/profile.log 2>&1
+bash tools/gpu_profile.sh "--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-configs --kernel-reps 2" all > gpurun_out/profile.log 2>&1
 tail -3 gpurun_out/profile.log
 python tools/pmc_summary.py gpurun_out solve_kernel > gpurun_out/pmc_summary.txt
 python tools/pmc_summary.py gpurun_out solve_kernel --json > gpurun_out/pmc.json
 cp gpurun_out/pmc.json profiles/${ROUND:-r01}_pmc.json   # bench.py reads roofline.traffic from the latest profiles/r*_pmc.json
 timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
-timeout 900 python tools/gpu_shortcut_stress.py > gpurun_out/stress.log 2>&1; grep total gpurun_out/stress.log
+timeout 900 python tools/gpu_shortcut_stress.py ${STRESS_ROUNDS:-2} > gpurun_out/stress.log 2>&1; grep total gpurun_out/stress.log
+timeout 600 python tools/gpu_near_parallel.py > gpurun_out/near_parallel.log 2>&1; tail -1 gpurun_out/near_parallel.log
+timeout 600 python tools/gpu_tolerance_report.py 2>/dev/null > gpurun_out/tolerance_report.json; tail -5 gpurun_out/tolerance_report.json
 if [ -f build_dbg/libtoppra_tim.so ]; then
   TOPPRA_HIP_LIB=build_dbg/libtoppra_tim.so timeout 300 python tools/gpu_cert_phases.py > gpurun_out/phases.log 2>&1; tail -3 gpurun_out/phases.log
 fi
 if [ -f build_dbg/libtoppra_dbg.so ]; then
   TOPPRA_HIP_LIB=build_dbg/libtoppra_dbg.so TPR_DEV_BUILD=1 timeout 300 python tools/gpu_shortcut_hitrate.py > gpurun_out/hitrate.log 2>&1; tail -3 gpurun_out/hitrate.log
+  TOPPRA_HIP_LIB=$PWD/build_dbg/libtoppra_dbg.so timeout 300 python tools/gpu_walk_fail.py > gpurun_out/walk_fail.log 2>&1; head -8 gpurun_out/walk_fail.log
 fi
