@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=5)
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="multi-rank control-flow rehearsal on ONE GPU: every rank uses cuda:0 and the gather runs over "
+                         "gloo on host copies (RCCL refuses two ranks on one device); timings are meaningless")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs block (C1-C4, host-buffer path)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary (full iteration, family 2) measurements (used under rocprofv3 so that the "
@@ -238,11 +241,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if (args.rehearsal and world > 1) else dev  # where collectives run
 
     B, d, N = args.batch, args.dof, args.gridpoints
     data = tb.make_synthetic_batch(B, d, N, seed=20240924 + rank)
@@ -253,12 +262,12 @@ def main():
     # N > 1: the only communication is the gather of sd^2 to rank 0 (RCCL); it is issued asynchronously so
     # that step k's gather rides the xGMI links while step k+1 is being solved (toppra_amd/distributed.py)
     from toppra_amd.distributed import PipelinedGather
-    gatherer = PipelinedGather(B, N + 1, torch.float64, dev) if world > 1 else None
+    gatherer = PipelinedGather(B, N + 1, torch.float64, cdev) if world > 1 else None
 
     def step():
         out = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], variant=args.variant)
         if gatherer is not None:
-            gatherer.submit(out["sd2"])
+            gatherer.submit(out["sd2"].to(cdev))
         return out
 
     def fence():
@@ -279,7 +288,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -305,18 +314,19 @@ def main():
     # so that an N > 1 line explains itself
     per_rank_kernel_ms = gather_alone_ms = None
     if world > 1:
-        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t = torch.zeros(world, dtype=torch.float64, device=cdev)
         t[rank] = kernel_ms
         dist.all_reduce(t)
         per_rank_kernel_ms = [float(v) for v in t.tolist()]
-        g2 = PipelinedGather(B, N + 1, torch.float64, dev)
-        g2.submit(out["sd2"]); g2.finish(); torch.cuda.synchronize(); dist.barrier()
+        g2 = PipelinedGather(B, N + 1, torch.float64, cdev)
+        sd2c = out["sd2"].to(cdev)
+        g2.submit(sd2c); g2.finish(); torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
         for _ in range(5):
-            g2.submit(out["sd2"])
+            g2.submit(sd2c)
             g2.finish()
         torch.cuda.synchronize()
-        tg = torch.tensor([(time.perf_counter() - t0) / 5 * 1e3], dtype=torch.float64, device=dev)
+        tg = torch.tensor([(time.perf_counter() - t0) / 5 * 1e3], dtype=torch.float64, device=cdev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather_alone_ms = float(tg.item())
 
@@ -342,7 +352,8 @@ def main():
                 "workload": "batch=%d per GPU, %d-DoF random cubic splines (5 waypoints), N=%d gridpoints, "
                             "JointVelocity+JointAcceleration(Interpolation), seidel path, fp64" % (B, d, N),
                 "global_batch": world * B, "dof": d, "gridpoints": N,
-                "parallelism": "shard%d+rccl_gather(sd2, overlapped with the next step)" % world if world > 1 else "single",
+                "parallelism": ("shard%d+rccl_gather(sd2, overlapped with the next step)" % world if world > 1 else "single")
+                               + (" [REHEARSAL on one GPU over gloo: timings meaningless]" if args.rehearsal else ""),
                 "kernel_variant": args.variant,
             },
             "waypoint_lps_per_s": 3 * N * traj_per_s,
