@@ -140,3 +140,28 @@ def test_reachable_sets_match_reference(reference, oracle, d, N, scheme, sds):
         oL, oX = w.compute_reachable_sets(*sds)
         assert_same(oL, L, "L")
         assert_same(oX, inst.problem_data.X, "X")
+
+
+def test_host_glue_matches_reference(reference):
+    """propose_gridpoints and ParametrizeSpline (vectorised host code here, loops in the reference) give the
+    reference's grids, knot times and spline coefficients value for value."""
+    import toppra.interpolator as ri
+    import toppra.parametrizer as rp
+    import toppra_amd as ta
+    from toppra_amd.interpolator import propose_gridpoints
+    rng = np.random.default_rng(0)
+    for t in range(20):
+        d, m = int(rng.integers(1, 8)), int(rng.integers(3, 9))
+        way = rng.standard_normal((m, d)) * float(rng.choice([0.1, 1, 5]))
+        p1 = ta.SplineInterpolator(np.linspace(0, 1, m), way)
+        p2 = reference.SplineInterpolator(np.linspace(0, 1, m), way)
+        kw = dict(max_err_threshold=float(rng.choice([1e-4, 1e-3, 1e-5])), max_seg_length=float(rng.choice([0.05, 0.02, 0.2])),
+                  min_nb_points=int(rng.choice([100, 30, 250])))
+        g1, g2 = propose_gridpoints(p1, **kw), ri.propose_gridpoints(p2, **kw)
+        assert np.array_equal(np.array(g1), np.array(g2))
+        sd = np.abs(rng.standard_normal(len(g1)))
+        sd[0] = sd[-1] = 0
+        if t % 3 == 0:
+            sd[5:8] = 0  # a standing stretch (the 5 s rule)
+        a, b = ta.ParametrizeSpline(p1, g1, sd), rp.ParametrizeSpline(p2, g2, sd)
+        assert np.array_equal(a.cspl.x, b.cspl.x) and np.array_equal(a.cspl.c, b.cspl.c)

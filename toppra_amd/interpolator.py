@@ -91,28 +91,24 @@ def spline_tables(path):
 
 def propose_gridpoints(path, max_err_threshold=1e-4, max_iteration=100, max_seg_length=0.05,
                        min_nb_points=100):
-    """Grid refinement by bisection until 0.5*max|q''|*ds^2 <= threshold on every segment, no
-    segment longer than max_seg_length, and at least min_nb_points points
-    (interpolator.py:49-122)."""
-    pts = [path.path_interval[0], path.path_interval[1]]
-    for iteration in range(max_iteration):
-        grew = False
-        for idx in range(len(pts) - 1):
-            lo, hi = pts[idx], pts[idx + 1]
-            mid = 0.5 * (lo + hi)
-            dist = hi - lo
-            if dist > max_seg_length:
-                pts.append(mid)
-                grew = True
-                continue
-            if np.max(np.abs(0.5 * path(mid, 2) * dist ** 2)) > max_err_threshold:
-                pts.append(mid)
-                grew = True
-        pts = sorted(pts)
-        if not grew:
+    """Gridpoints that cover ``path`` well enough (the reference's rule, interpolator.py:49-122): a segment
+    is halved while it is longer than ``max_seg_length`` or its estimated interpolation error
+    ``0.5 max|q''(mid)| ds^2`` exceeds ``max_err_threshold``; afterwards every segment is halved until
+    there are ``min_nb_points`` points.  One vectorised pass over all segments per refinement level (a
+    single path evaluation per level); the grids are the reference's, value for value."""
+    pts = np.array([path.path_interval[0], path.path_interval[1]], dtype=float)
+    converged = False
+    for _ in range(max_iteration):
+        lo, hi = pts[:-1], pts[1:]
+        mid, seg = 0.5 * (lo + hi), hi - lo
+        curv = np.abs(0.5 * np.reshape(path(mid, 2), (len(mid), -1)) * (seg ** 2)[:, None]).max(axis=1)
+        split = (seg > max_seg_length) | (curv > max_err_threshold)
+        if not split.any():
+            converged = True
             break
+        pts = np.sort(np.concatenate([pts, mid[split]]))
     while len(pts) < min_nb_points:
-        pts = sorted(pts + [0.5 * (pts[i] + pts[i + 1]) for i in range(len(pts) - 1)])
-    if iteration == max_iteration - 1:
+        pts = np.sort(np.concatenate([pts, 0.5 * (pts[:-1] + pts[1:])]))
+    if not converged:
         raise ValueError("Unable to find a good gridpoint for this path.")
-    return pts
+    return [float(v) for v in pts]

@@ -63,23 +63,19 @@ class ParametrizeConstAccel(AbstractGeometricPath):
 
 
 class ParametrizeSpline(SplineInterpolator):
-    """Cubic spline in time through q(s_i) at the gridpoint times, clamped to q'(s) sd at both
-    ends (parametrizer.py:161-196)."""
+    """Cubic spline in time through q(s_i) at the gridpoint time stamps, clamped to q'(s) sd at both ends
+    (parametrizer.py:161-196).  Host mirror of ``tpr_param_spline_batch`` (which BatchTOPPRA uses)."""
 
     def __init__(self, path, gridpoints, velocities):
-        gridpoints = np.asarray(gridpoints, dtype=float)
-        velocities = np.asarray(velocities, dtype=float)
-        t_grid = np.zeros_like(gridpoints)
-        skip = []
-        for i in range(1, len(t_grid)):
-            sd_avg = (velocities[i - 1] + velocities[i]) / 2
-            delta_t = (gridpoints[i] - gridpoints[i - 1]) / sd_avg if sd_avg > TINY else 5
-            t_grid[i] = t_grid[i - 1] + delta_t
-            if delta_t < TINY:
-                skip.append(i)
-        t_grid = np.delete(t_grid, skip)
-        gridpoints = np.delete(gridpoints, skip)
+        ss = np.asarray(gridpoints, dtype=float)
+        sd = np.asarray(velocities, dtype=float)
+        sd_avg = 0.5 * (sd[:-1] + sd[1:])
+        # a standing stretch counts 5 s; np.cumsum accumulates left to right, i.e. the reference's running sum
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dt = np.where(sd_avg > TINY, np.diff(ss) / np.where(sd_avg > TINY, sd_avg, 1.0), 5.0)
+        stamps = np.concatenate([[0.0], np.cumsum(dt)])
+        keep = np.concatenate([[True], dt >= TINY])   # gridpoints reached in no time are dropped
+        ends = path.path_interval
         super(ParametrizeSpline, self).__init__(
-            t_grid, path(gridpoints),
-            ((1, path(path.path_interval[0], 1) * velocities[0]),
-             (1, path(path.path_interval[1], 1) * velocities[-1])))
+            stamps[keep], path(ss[keep]),
+            ((1, path(ends[0], 1) * sd[0]), (1, path(ends[1], 1) * sd[-1])))
