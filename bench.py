@@ -233,6 +233,9 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from toppra_amd import build as hip_build
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        hip_build.ensure_built()  # no-op when the in-tree library travelled with the snapshot
     from toppra_amd import batch as tb
 
     rank = int(os.environ.get("RANK", "0"))
