@@ -236,6 +236,11 @@ def main():
     from toppra_amd import build as hip_build
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         hip_build.ensure_built()  # no-op when the in-tree library travelled with the snapshot
+    else:
+        for _ in range(600):      # the other ranks wait for rank 0's build instead of racing it
+            if os.path.exists(hip_build.LIB):
+                break
+            time.sleep(0.5)
     from toppra_amd import batch as tb
 
     rank = int(os.environ.get("RANK", "0"))
