@@ -222,6 +222,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=5)
+    ap.add_argument("--gather", choices=["auto", "overlap", "sequential"], default="auto",
+                    help="N > 1: where the gather of sd^2 goes relative to the next solve (auto: timed during warm-up)")
     ap.add_argument("--rehearsal", action="store_true",
                     help="multi-rank control-flow rehearsal on ONE GPU: every rank uses cuda:0 and the gather runs over "
                          "gloo on host copies (RCCL refuses two ranks on one device); timings are meaningless")
@@ -272,10 +274,20 @@ def main():
     from toppra_amd.distributed import PipelinedGather
     gatherer = PipelinedGather(B, N + 1, torch.float64, cdev) if world > 1 else None
 
+    # Two ways to place the gather: "overlap" (step k's gather rides the links while step k+1 is being solved)
+    # or "sequential" (the next solve is ordered after the gather).  The solve kernel is sized for exactly one
+    # wave per SIMD, so if the collective's own kernels occupy compute units while it runs, the displaced
+    # blocks need a second round and overlapping LOSES; which one wins depends on RCCL's channel count on the
+    # node.  "auto" times both during the warm-up steps (all ranks agree through a MAX all-reduce) and keeps
+    # the faster one for the timed region.
+    gather_mode = {"value": "overlap" if args.gather == "auto" else args.gather}
+
     def step():
         out = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], variant=args.variant)
         if gatherer is not None:
             gatherer.submit(out["sd2"].to(cdev))
+            if gather_mode["value"] == "sequential":
+                gatherer.order_after()  # stream-level: the next solve waits for this gather (no host block)
         return out
 
     def fence():
@@ -287,8 +299,25 @@ def main():
         torch.cuda.synchronize()
 
     out = None
-    for _ in range(args.warmup):
-        out = step()
+    calibration = None
+    if world > 1 and args.gather == "auto" and args.warmup >= 4:
+        timings = {}
+        for mode, n in (("overlap", (args.warmup + 1) // 2), ("sequential", args.warmup // 2)):
+            gather_mode["value"] = mode
+            out = step()  # first step of a mode is not timed (buffers, lazy init)
+            fence()
+            tc = time.perf_counter()
+            for _ in range(max(1, n - 1)):
+                out = step()
+            fence()
+            tm = torch.tensor([(time.perf_counter() - tc) / max(1, n - 1)], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            timings[mode] = float(tm.item()) * 1e3
+        gather_mode["value"] = min(timings, key=timings.get)
+        calibration = {"ms_per_step": timings, "chosen": gather_mode["value"]}
+    else:
+        for _ in range(args.warmup):
+            out = step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -360,11 +389,12 @@ def main():
                 "workload": "batch=%d per GPU, %d-DoF random cubic splines (5 waypoints), N=%d gridpoints, "
                             "JointVelocity+JointAcceleration(Interpolation), seidel path, fp64" % (B, d, N),
                 "global_batch": world * B, "dof": d, "gridpoints": N,
-                "parallelism": ("shard%d+rccl_gather(sd2, overlapped with the next step)" % world if world > 1 else "single")
+                "parallelism": ("shard%d+rccl_gather(sd2, %s)" % (world, gather_mode["value"]) if world > 1 else "single")
                                + (" [REHEARSAL on one GPU over gloo: timings meaningless]" if args.rehearsal else ""),
                 "kernel_variant": args.variant,
             },
             "waypoint_lps_per_s": 3 * N * traj_per_s,
+            "gather_placement": (calibration or {"chosen": gather_mode["value"]}) if world > 1 else None,
             "per_rank_kernel_ms": per_rank_kernel_ms,
             "gather_alone_ms": gather_alone_ms,
             "secondary_measured": (not args.no_secondary) and world == 1,

@@ -85,8 +85,13 @@ def _pipeline_worker(rank, world, port, tmp):
     for step in range(5):  # step k's gather overlaps step k+1's "solve"
         local = torch.full((4, 3), float(10 * step + rank), dtype=torch.float64)
         pg.submit(local)
-        if rank == 0 and step > 0:
-            pass  # buffers of step k-1 may already be overwritten; only the last step is inspected
+        if step % 2 == 1:
+            # "sequential" placement (bench.py --gather sequential): the next solve is ordered after this gather;
+            # afterwards the receive buffers hold this step's rows
+            pg.order_after()
+            if rank == 0:
+                for r in range(world):
+                    assert torch.equal(pg.bufs[r], torch.full((4, 3), float(10 * step + r), dtype=torch.float64))
     bufs = pg.finish()
     if rank == 0:
         assert len(bufs) == world

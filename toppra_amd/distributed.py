@@ -108,6 +108,13 @@ class PipelinedGather:
         work = self._dist.gather(local, self.bufs, dst=self.dst, group=self.group, async_op=True)
         self._pending = (work, local)
 
+    def order_after(self):
+        """Order the caller's subsequent work after the gather in flight (RCCL: a stream-level wait on torch's
+        current stream, the host does not block; gloo: a host wait)."""
+        if self._pending is not None and self._pending[0] is not None:
+            self._pending[0].wait()
+            self._pending = (None, self._pending[1])
+
     def _wait(self):
         if self._pending is not None and self._pending[0] is not None:
             self._pending[0].wait()
