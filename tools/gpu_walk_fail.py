@@ -37,3 +37,6 @@ for needy in (0, 1):
             for b in range(3):
                 v = t[needy * 32 + same * 16 + a * 4 + b]
                 if v: print("  %s %s  %-22s -> %-22s %8.3f" % ("needy " if needy else "lane  ", "same pair" if same else "new pair ", names3[a], names3[b], v / B))
+why = h[4][100:108]
+print("why the lane-level certificate of the PROPOSED pair failed (per trajectory):",
+      {n: round(int(v) / B, 3) for n, v in zip(["-", "unusable pair", "dual infeasible", "row violated", "row in tolerance band", "guards", "-", "-"], why) if v})

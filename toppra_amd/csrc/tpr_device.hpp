@@ -125,6 +125,9 @@ struct Lp2dOut {
     bool ok;
     double u, x;
     int ac0, ac1;
+#ifdef TPR_DEBUG_PREDICT
+    int why = 0;  // debug builds: why a certificate failed (tpr_cert.hip.inc)
+#endif
 };
 
 // Incremental (Seidel) 2-variable LP in the reference's deterministic order.

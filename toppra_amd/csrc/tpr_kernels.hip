@@ -235,7 +235,7 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
     // the shared grid goes to LDS only while four blocks still fit a CU (160 KB): a fifth of the
     // 1024 blocks of a 65536-trajectory batch would otherwise wait for a second round
     const size_t grid_bytes = (size_t)(A.N + 1) * sizeof(double);
-    const size_t static_lds = (((6 * D + 6) > 24 ? (6 * D + 6) : 24) * BS + tpr::kCertXch * BS + tpr::kCertBatchGroups * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
+    const size_t static_lds = (((6 * D + 6) > 24 ? (6 * D + 6) : 24) * BS + tpr::kCertXch * BS + tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
     const bool grid_lds = !(A.flags & TPR_GRID_PER_TRAJ) && static_lds + grid_bytes <= 40 * 1024;
     const size_t lds = grid_lds ? grid_bytes : 0;
     // One 64-lane block per wave; ~33 KB of LDS per block leaves one wave per SIMD, which the kernel
