@@ -42,6 +42,12 @@ def main():
     print("%d trajectories in %.1f ms (host buffers, incl. transfers); %d Ok" % (B, dt * 1e3, sum(c.name == "Ok" for c in codes)))
     print("durations: min %.3f  mean %.3f  max %.3f s" % (ts[:, -1].min(), ts[:, -1].mean(), ts[:, -1].max()))
     print("q(t) of trajectory 0 at 5 instants:\n", np.round(q[0, ::12], 4))
+    if args.desired_duration is None:
+        # the reference's default output: a cubic spline in time through the gridpoints (ParametrizeSpline), GPU end to end
+        traj = bt.compute_trajectory()
+        dur = traj.duration
+        qs = traj(np.linspace(0, 1, 50)[None, :] * dur[:, None], order=1)
+        print("ParametrizeSpline: durations mean %.3f s, max |dq/dt| of trajectory 0 = %.3f" % (dur.mean(), np.abs(qs[0]).max()))
 
 
 if __name__ == "__main__":
