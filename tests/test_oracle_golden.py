@@ -91,3 +91,16 @@ def test_sd_fixture_oracle(oracle, name):
     assert_same(out["K"], fx["K"], "K")
     assert_same(np.sqrt(out["sd2"]), fx["sd"], "sd")
     assert_same(out["u"], fx["u"], "u")
+
+
+@pytest.mark.parametrize("name", ["reach_d5_N60", "reach_d3_N40_collocation"])
+def test_oracle_reachable_sets_vs_reference_fixture(oracle, name):
+    """compute_reachable_sets of the oracle against the real reference's outputs (tools/make_golden.py)."""
+    fx = golden(name)
+    interp = bool(int(fx["interpolation"]))
+    flags = oracle.FLAG_VEL | oracle.FLAG_ACC | (oracle.FLAG_INTERP if interp else 0)
+    for b in range(fx["coef"].shape[0]):
+        w = oracle.Wrapper(fx["coef"][b], fx["breaks"], fx["grid"], fx["vlim"][b], fx["alim"][b], flags=flags)
+        L, X = w.compute_reachable_sets(float(fx["sdmin"][b]), float(fx["sdmax"][b]))
+        assert_same(L, fx["L"][b], "L[%d]" % b)
+        assert_same(X, fx["X"][b], "X[%d]" % b)
