@@ -22,3 +22,10 @@ print("cycles per wave (mean over lanes) for B=%d d=%d N=%d:" % (B, d, N))
 for n, v in sorted(zip(names, m), key=lambda p: -p[1]):
     print("  %-50s %12.0f  %5.1f%%   per stage %8.0f" % (n, v, 100 * v / m.sum(), v / N))
 print("  total %.0f cycles = %.3f ms at 2.4 GHz" % (m.sum(), m.sum() / 2.4e6))
+it = out["u"][:, 12:14]
+print("  forward LP: the wave repeats it while any lane retries (reference: lower x_i and solve again): %.4f passes per stage; "
+      "lanes with a retry anywhere: %.2f%%, retries per trajectory %.3f" % (it[:, 0].mean() / N, 100 * (it[:, 1] > 0).mean(), it[:, 1].mean()))
+be = out["u"][:, 14:16]
+bt = m[[2, 4, 5, 6, 10, 11]].sum()
+print("  batches: entered at %.1f%% of the stages (%.2f LPs per entry); %.0f cycles per entry" % (
+    100 * be[:, 0].mean() / N, be[:, 1].mean() / max(be[:, 0].mean(), 1e-9), bt / max(be[:, 0].mean(), 1e-9)))
