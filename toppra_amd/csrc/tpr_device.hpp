@@ -59,6 +59,14 @@ __device__ __forceinline__ void cubic_d1_d2(double c0, double c1, double c2, dou
     q2 = e1 + e0 * t;
 }
 
+// The same from the derivative's coefficients d0 = 3 c0, d1 = 2 c1, d2 = c2 (segment constants: a kernel that keeps
+// a segment's coefficients in registers scales them once per segment instead of once per gridpoint).
+__device__ __forceinline__ void cubic_d1_d2_scaled(double d0, double d1, double d2, double t, double &q1, double &q2) {
+    const double e0 = d0 * 2.0, e1 = d1;
+    q1 = (d2 + d1 * t) + d0 * (t * t);
+    q2 = e1 + e0 * t;
+}
+
 __device__ inline void path_eval(const Traj &T, double s, double *q1, double *q2) {
     const int j = find_segment(T.breaks, T.nseg, s);
     const double t = s - T.breaks[j];
