@@ -133,6 +133,7 @@ struct Lp2dOut {
     bool ok;
     double u, x;
     int ac0, ac1;
+    bool hint_full = false;  // family 3: the vertex looked optimal but could not be certified -- skip the walk, iterate
 #ifdef TPR_DEBUG_PREDICT
     int why = 0;  // debug builds: why a certificate failed (tpr_cert.hip.inc)
 #endif
