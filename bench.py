@@ -207,7 +207,8 @@ def baseline_configs(torch, tb, dev):
     res["host_buffers_65536x7x200"] = {
         "all_outputs_ms": wall(lambda: tb.solve_batch(*hargs), 3),
         "without_K_ms": wall(lambda: tb.solve_batch(*hargs, want_K=False), 3),
-        "note": "PCIe-inclusive wall time of tpr_solve_batch with host pointers (page-locked result arrays); never `value`"}
+        "sd2_only_ms": wall(lambda: tb.solve_batch(*hargs, want_K=False, want_u=False), 3),
+        "note": "PCIe-inclusive wall time of tpr_solve_batch with host pointers (page-locked result arrays); never `value`.  sd2_only: neither K nor u returned -- all that retiming (compute_trajectory) reads"}
     return res
 
 

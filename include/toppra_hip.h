@@ -83,7 +83,8 @@ typedef struct tpr_problem {
 typedef struct tpr_result {
     double *sd2;     /* [B][N+1]    x_i = sd_i^2           (may be NULL)                          */
     double *sd;      /* [B][N+1]    sd_vec = sqrt(x)       (may be NULL)                          */
-    double *u;       /* [B][N]      sdd_vec                (may be NULL)                          */
+    double *u;       /* [B][N]      sdd_vec                (may be NULL; tpr_solve_batch keeps it in a
+                                                            workspace then, like K)                 */
     double *K;       /* [B][N+1][2] controllable sets      (may be NULL for tpr_solve_batch: kept in
                                                             a stream-ordered workspace then)        */
     int32_t *status; /* [B]                                (may be NULL)                          */

@@ -176,6 +176,10 @@ def test_K_is_optional_and_inputs_are_validated(gpu):
         assert "K" not in lean
         for k in ("sd2", "u", "status"):
             assert np.array_equal(lean[k], full[k], equal_nan=True), (variant, k)
+        leaner = batch.solve_batch(*args, want_K=False, want_u=False, variant=variant)  # what retiming reads: sd2 only
+        assert "u" not in leaner and "K" not in leaner
+        for k in ("sd2", "status"):
+            assert np.array_equal(leaner[k], full[k], equal_nan=True), (variant, k)
     scalar = batch.solve_batch(*args, sd_start=0.0, sd_end=0.05)           # scalars broadcast to [B]
     vec = batch.solve_batch(*args, sd_start=np.zeros(300), sd_end=np.full(300, 0.05))
     assert np.array_equal(scalar["sd2"], vec["sd2"], equal_nan=True)

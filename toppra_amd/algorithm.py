@@ -251,11 +251,13 @@ class BatchTOPPRA(object):
             gridpoints = np.asarray(gridpoints, dtype=np.float64)
         return cls(coef, breaks, gridpoints, vlim, alim, **kw)
 
-    def compute_parameterization(self, sd_start=None, sd_end=None, want_sd=True, variant=0):
+    def compute_parameterization(self, sd_start=None, sd_end=None, want_sd=True, variant=0, want_K=True, want_u=True):
         """dict(sd2, sd, u, K, status): per-trajectory results; status 0/1/2 = Ok /
-        FailUncontrollable / ErrUnknown, failed rows NaN-filled."""
+        FailUncontrollable / ErrUnknown, failed rows NaN-filled.  ``want_K`` / ``want_u`` = False leave the
+        controllable sets / path accelerations in a device workspace (fewer bytes back to a host caller)."""
         return _batch.solve_batch(self.coef, self.breaks, self.gridpoints, self.vlim, self.alim,
-                                  sd_start, sd_end, self.interpolation, want_sd=want_sd, variant=variant)
+                                  sd_start, sd_end, self.interpolation, want_sd=want_sd, variant=variant,
+                                  want_K=want_K, want_u=want_u)
 
     def compute_parameterization_sd(self, desired_duration, sd_start=None, sd_end=None, atol=1e-5):
         """TOPPRAsd for the batch: dict(sd2, sd, u, K, status, alpha)."""
@@ -268,7 +270,7 @@ class BatchTOPPRA(object):
         "ParametrizeSpline" (its default) or "ParametrizeConstAccel" -- entirely on the GPU.  Returns a
         :class:`BatchTrajectory`; trajectories that could not be parameterized have ``status != 0`` and
         NaN durations (the reference returns None for them)."""
-        res = self.compute_parameterization(sd_start, sd_end, want_sd=True)
+        res = self.compute_parameterization(sd_start, sd_end, want_sd=True, want_K=False, want_u=False)  # retiming reads sd only
         if parametrizer == "ParametrizeSpline":
             sp = _batch.param_spline_batch(self.coef, self.breaks, self.gridpoints, res["sd"])
             return BatchTrajectory("spline", res, self, spline=sp)

@@ -56,13 +56,14 @@ def _prepare(coef):
 
 
 def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
-                want_sd=False, variant=0, strict=False, want_K=True):
+                want_sd=False, variant=0, strict=False, want_K=True, want_u=True):
     """compute_parameterization for B trajectories.
 
     Returns dict(sd2[B,N+1], u[B,N], K[B,N+1,2], status[B] (+ sd[B,N+1] if want_sd)); failed
     trajectories are NaN-filled with status 1 (FailUncontrollable) or 2 (ErrUnknown).
     ``want_K=False`` leaves the controllable sets in a device workspace (half of the output bytes of a
-    host-buffer call).
+    host-buffer call); ``want_u=False`` the path accelerations too -- retiming (``compute_trajectory``)
+    needs neither.
 
     ``strict=True`` (TPR_STRICT_SEIDEL) runs every stage LP through the reference's full Seidel
     iteration instead of answering it from a certified optimal vertex (same bits, slower)."""
@@ -70,12 +71,14 @@ def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, inte
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
                                  variant, strict=strict)
     B, N = p.B, p.N
-    out = {"sd2": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)), "status": _empty(coef, (B,), "i32")}
+    out = {"sd2": _empty(coef, (B, N + 1)), "status": _empty(coef, (B,), "i32")}
+    if want_u:
+        out["u"] = _empty(coef, (B, N))
     if want_K:
         out["K"] = _empty(coef, (B, N + 1, 2))
     if want_sd:
         out["sd"] = _empty(coef, (B, N + 1))
-    r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out["u"]),
+    r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out.get("u")),
                          K=_capi.ptr(out.get("K")), status=_capi.ptr(out["status"]))
     _capi.check(_capi.load().tpr_solve_batch(C.byref(p), C.byref(r), _stream_ptr(coef)))
     return out

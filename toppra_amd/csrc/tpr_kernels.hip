@@ -444,18 +444,19 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream_) {
     const size_t B = (size_t)p->B, N = (size_t)p->N;
     A.sd2 = S.out(r->sd2, B * (N + 1));
     A.sd = S.out(r->sd, B * (N + 1));
-    A.u = S.out(r->u, B * N);
     A.status = S.out(r->status, B);
-    if (r->K) {
-        A.K = S.out(r->K, B * (N + 1) * 2);
-    } else if (B > 0) {
-        // the caller does not want the controllable sets: the forward scan still reads them, so they live in
-        // a stream-ordered workspace (no host copy, no caller buffer; half of the output bytes of a host call)
+    // outputs the caller does not want (the controllable sets, which the forward scan still reads; the path
+    // accelerations, which retiming -- compute_trajectory -- never looks at) live in a stream-ordered workspace:
+    // no host copy, no caller buffer, and the fast kernel family still serves the call
+    auto workspace = [&](size_t doubles) -> double * {
         void *ws = nullptr;
-        if (S.err == hipSuccess) S.err = hipMallocAsync(&ws, B * (N + 1) * 2 * sizeof(double), stream);
+        if (doubles == 0) return nullptr;
+        if (S.err == hipSuccess) S.err = hipMallocAsync(&ws, doubles * sizeof(double), stream);
         if (S.err == hipSuccess) S.owned.push_back(ws);
-        A.K = static_cast<double *>(ws);
-    }
+        return static_cast<double *>(ws);
+    };
+    A.u = r->u ? S.out(r->u, B * N) : workspace(B * N);
+    A.K = r->K ? S.out(r->K, B * (N + 1) * 2) : workspace(B * (N + 1) * 2);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (int rc = launch_solve(p, A, stream)) return rc;
     HIP_TRY(S.finish());
