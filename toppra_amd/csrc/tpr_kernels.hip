@@ -322,9 +322,10 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
     if (A.B == 0) return TPR_E_OK;
     int variant = p->variant;
     // auto: family 3 finishes up to 65536 trajectories (one wave per SIMD) in one fixed-latency round,
-    // which beats family 2's throughput from about half that batch upward; smaller batches spread
-    // better over the chip with family 2's 8 lanes per trajectory
-    if (variant == 0) variant = (cert_supported(A) && A.B >= 32768) ? 3 : (group_supported(A) ? 2 : 1);
+    // which beats family 2's throughput from about a quarter of that batch upward (tools/gpu_crossover.py:
+    // 12 288: 1.65 vs 1.63 ms, 16 384: 1.71 vs 1.64, 20 480: 2.17 vs 1.68); smaller batches spread better
+    // over the chip with family 2's 8 lanes per trajectory
+    if (variant == 0) variant = (cert_supported(A) && A.B >= 14336) ? 3 : (group_supported(A) ? 2 : 1);
     switch (variant) {
         case 3: {
             if (!cert_supported(A))
