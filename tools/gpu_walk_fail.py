@@ -40,15 +40,9 @@ for needy in (0, 1):
 why = h[4][100:108]
 print("why the lane-level certificate of the PROPOSED pair failed (per trajectory):",
       {n: round(int(v) / B, 3) for n, v in zip(["-", "unusable pair", "dual infeasible", "row violated", "row in tolerance band", "guards", "-", "-"], why) if v})
-print("where the batches' answer sits relative to the lane-level search (warm pair p, q; blockers rp along p's line, rq along q's), per trajectory:")
-lab = ["p", "q", "rp", "rq"]
+print("where the batches' answer sits relative to the lane-level search (warm pair p, q; L = the row whose line was searched, w = its blocker), per trajectory:")
+lab = ["p", "q", "L", "w"]
 for w, wn in enumerate(["-", "unusable pair", "dual infeasible", "row violated", "row in tolerance band", "guards", "-", "-"]):
     row = h[4][128 + 16 * w:128 + 16 * w + 16]
     if row.sum():
         print("  %-22s" % wn, {"+".join(l for i, l in enumerate(lab) if c >> i & 1) or "none": round(int(v) / B, 3) for c, v in enumerate(row) if v})
-fl = h[4][256:512]
-names_f = ["viol", "okp", "okq", "cp", "cq", "use_p", "use_q", "both"]
-print("'row violated' with the answer at the two blockers: the search's flags")
-for c in np.argsort(-fl)[:12]:
-    if fl[c]: print("   %-40s %.4f" % (" ".join(n for i, n in enumerate(names_f) if c >> i & 1) or "-", fl[c] / B))
-print("   other blocker at the proposed vertex: violated / within 1e-9 / satisfied:", [round(int(v) / B, 4) for v in (h[3][401 + 2], h[3][400 + 2], h[3][400])])
