@@ -82,6 +82,27 @@ def test_lower_bound_shortcut_is_exact(gpu, B, d, N, seed):
                 assert np.array_equal(fast[k], full[k], equal_nan=True), (variant, k)
 
 
+@pytest.mark.parametrize("B,d,N,seed", [(65536, 7, 200, 21), (20480, 4, 120, 22), (16384, 8, 64, 23)])
+def test_collocation_on_the_certified_lane_kernel(gpu, B, d, N, seed):
+    """Collocation at full size: the certified lane kernel (the interpolation blocks are null rows there; default
+    from 14 336 trajectories) against the full Seidel iteration of family 2 (disabled rows), bit for bit, with
+    and without the velocity constraint, incl. non-zero boundary velocities and badly scaled paths."""
+    data = batch.make_synthetic_batch(B, d, N, seed=seed)
+    rng = np.random.default_rng(seed)
+    sd0 = np.where(rng.random(B) < 0.3, 0.1 * rng.random(B), 0.0)
+    sd1 = np.where(rng.random(B) < 0.3, 0.3 * rng.random(B), 0.0)
+    scale = 10.0 ** rng.uniform(-6, 0, size=(B, 1, 1, 1))
+    for coef, vlim, s0, s1 in ((data["coef"], data["vlim"], sd0, sd1), (data["coef"] * scale, data["vlim"], None, None),
+                               (data["coef"], None, None, sd1)):
+        args = (coef, data["breaks"], data["grid"], vlim, data["alim"], s0, s1, False)
+        full = batch.solve_batch(*args, strict=True)
+        for kw in (dict(variant=3), dict()):
+            fast = batch.solve_batch(*args, **kw)
+            for k in ("K", "sd2", "u", "status"):
+                assert np.array_equal(fast[k], full[k], equal_nan=True), (kw, k)
+        assert (full["status"] == 0).any()
+
+
 @pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_certified_lane_kernel_all_dofs(gpu, oracle, d):
     """Kernel family 3 for every dof it serves, odd batch sizes (idle lanes), per-trajectory grids and

@@ -16,8 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _variants(d, interp, has_vel=True):
     # 1 generic lane kernel; 2 rows across lanes (8 lanes up to 8 dof, 16 above); 3 certified lane kernel
-    if not interp:
-        return [1, 2]  # Collocation: rows across lanes with the interpolation blocks disabled
+    # Collocation: the interpolation blocks are disabled rows (family 2) / null rows (family 3)
     return [1, 2, 3] if d <= 8 else [1, 2]
 
 

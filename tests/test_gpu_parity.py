@@ -86,9 +86,8 @@ def test_empty_batch_and_bad_arguments(gpu):
     wide = batch.make_synthetic_batch(8, 12, 20)  # d > 8: 16 lanes per trajectory
     assert batch.solve_batch(wide["coef"], wide["breaks"], wide["grid"], wide["vlim"], wide["alim"],
                              variant=2)["status"].shape == (8,)
-    with pytest.raises(_capi.ToppraHipError):  # the certified lane kernel refuses Collocation when forced
-        batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"],
-                          interpolation=False, variant=3)
+    with pytest.raises(_capi.ToppraHipError):  # the certified lane kernel needs an acceleration constraint
+        batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], None, variant=3)
     with pytest.raises(_capi.ToppraHipError):  # rows across lanes stop at 16 dof when forced
         big = batch.make_synthetic_batch(2, 20, 10)
         batch.solve_batch(big["coef"], big["breaks"], big["grid"], big["vlim"], big["alim"], variant=2)
@@ -138,7 +137,10 @@ def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
     flags = (FLAG_VEL if vlim is not None else 0) | (FLAG_ACC if alim is not None else 0) | (FLAG_INTERP if interp else 0)
     args = (data["coef"], data["breaks"], data["grid"], vlim, alim, None, sd1, interp)
     lane = batch.solve_batch(*args, variant=1)
-    for kw in (dict(variant=2), dict(variant=2, strict=True), dict()):
+    kws = [dict(variant=2), dict(variant=2, strict=True), dict()]
+    if alim is not None and d <= 8:
+        kws.append(dict(variant=3))  # the certified lane kernel: Interpolation and Collocation, velocity optional
+    for kw in kws:
         got = batch.solve_batch(*args, **kw)
         for k in ("K", "sd2", "u", "status"):
             assert np.array_equal(got[k], lane[k], equal_nan=True), (kw, k)

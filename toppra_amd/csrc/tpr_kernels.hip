@@ -222,7 +222,7 @@ int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
 // The certified lane kernel (family 3) serves the same constraint set up to 8 dof when sd2, u and
 // status are requested; the strict mode stays with family 2.
 bool cert_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && interp_rows(A) && A.d <= 8 && !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
+    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= 8 && !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
            (A.backward_only || (A.sd2 && A.u && A.status));
 }
 
@@ -240,9 +240,14 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
     const size_t lds = grid_lds ? grid_bytes : 0;
     // One 64-lane block per wave; ~33 KB of LDS per block leaves one wave per SIMD, which the kernel
     // is written for (the whole register file, stalls covered by unrolled independent row work).
-#define TPR_LAUNCH_CERT(SD, GL) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, SD, GL>), grid, block, lds, stream, G)
-    if (A.sd) { if (grid_lds) TPR_LAUNCH_CERT(true, true); else TPR_LAUNCH_CERT(true, false); }
-    else { if (grid_lds) TPR_LAUNCH_CERT(false, true); else TPR_LAUNCH_CERT(false, false); }
+#define TPR_LAUNCH_CERT(SD, GL, IN) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, SD, GL, IN>), grid, block, lds, stream, G)
+    if (A.flags & TPR_ACC_INTERPOLATION) {
+        if (A.sd) { if (grid_lds) TPR_LAUNCH_CERT(true, true, true); else TPR_LAUNCH_CERT(true, false, true); }
+        else { if (grid_lds) TPR_LAUNCH_CERT(false, true, true); else TPR_LAUNCH_CERT(false, false, true); }
+    } else {  // Collocation
+        if (A.sd) { if (grid_lds) TPR_LAUNCH_CERT(true, true, false); else TPR_LAUNCH_CERT(true, false, false); }
+        else { if (grid_lds) TPR_LAUNCH_CERT(false, true, false); else TPR_LAUNCH_CERT(false, false, false); }
+    }
 #undef TPR_LAUNCH_CERT
     return TPR_E_OK;
 }
