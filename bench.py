@@ -301,9 +301,11 @@ def main():
 
     out = None
     calibration = None
-    if world > 1 and args.gather == "auto" and args.warmup >= 4:
+    if world > 1 and args.gather == "auto":
+        # (at least two steps per placement -- one untimed, one timed -- even when fewer warm-up steps were asked
+        # for: extra untimed steps do not touch the timed region)
         timings = {}
-        for mode, n in (("overlap", (args.warmup + 1) // 2), ("sequential", args.warmup // 2)):
+        for mode, n in (("overlap", max(2, (args.warmup + 1) // 2)), ("sequential", max(2, args.warmup // 2))):
             gather_mode["value"] = mode
             out = step()  # first step of a mode is not timed (buffers, lazy init)
             fence()
