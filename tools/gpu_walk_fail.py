@@ -46,3 +46,5 @@ for w, wn in enumerate(["-", "unusable pair", "dual infeasible", "row violated",
     row = h[4][128 + 16 * w:128 + 16 * w + 16]
     if row.sum():
         print("  %-22s" % wn, {"+".join(l for i, l in enumerate(lab) if c >> i & 1) or "none": round(int(v) / B, 3) for c, v in enumerate(row) if v})
+gd = h[3][416:448]
+print("verified vertices refused by a guard (per trajectory):", {"+".join(n for i, n in enumerate(["parallel row", "|v1d|", "violation bound", "row 5 in the band (pair not warm)", "limit range"]) if c >> i & 1) or "other (norms, roles, exact test)": round(int(v) / B, 4) for c, v in enumerate(gd) if v})
