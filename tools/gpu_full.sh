@@ -11,7 +11,10 @@ timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -5 | tee gpurun_out/pyt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 timeout 600 python tools/gpu_measure.py 2>/dev/null > gpurun_out/measure.json; tail -5 gpurun_out/measure.json
 rm -rf gpurun_out/prof_*
-bash tools/gpu_profile.sh "--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-configs --kernel-reps 2" all > gpurun_out/profile.log 2>&1
+# kernel trace over the bench's default step counts (the averages then agree with bench.py's own HIP-event time; the
+# first launches of a short run are 5-10 % slower), counters over a short run
+bash tools/gpu_profile.sh "--no-cpu-baseline --no-secondary --no-configs" stats > gpurun_out/profile.log 2>&1
+bash tools/gpu_profile.sh "--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-configs --kernel-reps 2" pmc >> gpurun_out/profile.log 2>&1
 tail -3 gpurun_out/profile.log
 python tools/pmc_summary.py gpurun_out solve_kernel > gpurun_out/pmc_summary.txt
 python tools/pmc_summary.py gpurun_out solve_kernel --json > gpurun_out/pmc.json
