@@ -49,6 +49,13 @@ __device__ __forceinline__ int find_segment(const double *breaks, int nseg, doub
     return j;
 }
 
+// 1 / d to a few ulp (hardware estimate + one Newton step; 4 instructions where the IEEE sequence takes 11).  Only for
+// values that feed searches and margin tests -- a vertex to test residuals at, a candidate bound -- never an output.
+__device__ __forceinline__ double rcp_approx(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+
 // q'(s), q''(s) of one dof from its four cubic coefficients (highest power first) at local
 // parameter t.  Power-basis accumulation in scipy's order, not Horner.
 __device__ __forceinline__ void cubic_d1_d2(double c0, double c1, double c2, double t, double &q1,
