@@ -6,6 +6,7 @@ limits, joints that stand still, non-uniform knots and grids, non-zero boundary 
 import os, sys
 import numpy as np
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 1   # repeat everything with fresh seeds
+VARIANT = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0: the default path; 2: the rows-across-lanes family with its shortcuts
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toppra_amd import batch
 
@@ -18,7 +19,7 @@ for rnd in range(ROUNDS):
       logs = rng.uniform(-5, 0.5, size=B)
       scale = (10.0 ** logs)[:, None, None, None]
       args = (data["coef"] * scale, data["breaks"], data["grid"], data["vlim"], data["alim"])
-      fast = batch.solve_batch(*args)
+      fast = batch.solve_batch(*args, variant=VARIANT)
       full = batch.solve_batch(*args, strict=True)
       bad = np.zeros(B, bool)
       for k in ("K", "sd2", "u"):
@@ -53,7 +54,7 @@ for rnd in range(ROUNDS):
       sd0 = np.where(rng.random(B) < 0.4, 0.3 * rng.random(B), 0.0)
       sd1 = np.where(rng.random(B) < 0.4, 0.3 * rng.random(B), 0.0)
       args = (coef, breaks, grid, vlim, alim, sd0, sd1)
-      fast = batch.solve_batch(*args)
+      fast = batch.solve_batch(*args, variant=VARIANT)
       full = batch.solve_batch(*args, strict=True)
       bad = np.zeros(B, bool)
       for k in ("K", "sd2", "u"):
