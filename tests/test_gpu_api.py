@@ -171,7 +171,7 @@ def test_K_is_optional_and_inputs_are_validated(gpu):
     data = batch.make_synthetic_batch(300, 5, 40, seed=11)
     args = (data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
     full = batch.solve_batch(*args)
-    for variant in (0, 2, 3):
+    for variant in (0, 2, 3, 4):
         lean = batch.solve_batch(*args, want_K=False, variant=variant)
         assert "K" not in lean
         for k in ("sd2", "u", "status"):

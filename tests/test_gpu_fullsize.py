@@ -52,9 +52,9 @@ def test_full_size_properties(gpu, oracle, B, d, N):
     assert np.array_equal(out["status"][idx], ref["status"])
     for k in ("K", "sd2", "u"):
         assert np.array_equal(out[k][idx], ref[k], equal_nan=True), k
-    # the three kernel families agree bit for bit on a 4096 slice (the default is family 3 here)
+    # the kernel families agree bit for bit on a 4096 slice (the default is family 3 at 65536, family 4 at 4096)
     sl = slice(0, 4096)
-    for variant in (1, 2):
+    for variant in (1, 2, 4):
         v = batch.solve_batch(data["coef"][sl], data["breaks"], data["grid"], data["vlim"][sl], data["alim"][sl],
                               variant=variant)
         for k in ("K", "sd2", "u", "status"):
@@ -76,7 +76,9 @@ def test_lower_bound_shortcut_is_exact(gpu, B, d, N, seed):
         args = (coef, data["breaks"], data["grid"], data["vlim"], data["alim"], s0, s1)
         full = batch.solve_batch(*args, strict=True)
         assert len(np.unique(full["status"])) >= (1 if s0 is not None else 2)
-        for variant in (2, 3):  # rows-across-lanes with shortcuts; certified lane kernel (default for large batches, d <= 8)
+        # rows-across-lanes with shortcuts; certified lane kernel (default for large batches, d <= 8); one trajectory
+        # per wave (default for small batches)
+        for variant in (2, 3, 4):
             fast = batch.solve_batch(*args, variant=variant)
             for k in ("K", "sd2", "u", "status"):
                 assert np.array_equal(fast[k], full[k], equal_nan=True), (variant, k)

@@ -15,9 +15,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _variants(d, interp, has_vel=True):
-    # 1 generic lane kernel; 2 rows across lanes (8 lanes up to 8 dof, 16 above); 3 certified lane kernel
-    # Collocation: the interpolation blocks are disabled rows (family 2) / null rows (family 3)
-    return [1, 2, 3] if d <= 8 else [1, 2]
+    # 1 generic lane kernel; 2 rows across lanes (8 lanes up to 8 dof, 16 above); 3 certified lane kernel;
+    # 4 one trajectory per wave (the latency kernel: every dof and constraint set)
+    # Collocation: the interpolation blocks are disabled rows (families 2, 4) / null rows (family 3)
+    return [1, 2, 3, 4] if d <= 8 else [1, 2, 4]
 
 
 @pytest.mark.parametrize("name", batch_fixtures())
@@ -44,7 +45,7 @@ def test_example_kinematics(gpu, tag):
     fx = golden("example_kinematics_seed9")
     grid = fx[tag + "_grid"]
     d = fx["coef"].shape[3]
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         got = batch.solve_batch(fx["coef"], fx["breaks"], grid, fx["vlim"], fx["alim"], want_sd=True,
                                 variant=variant)
         assert got["status"][0] == 0

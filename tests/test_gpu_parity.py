@@ -25,7 +25,7 @@ def _compare(got, ref, exact=True):
             assert np.array_equal(g, r, equal_nan=True), (key, "not bit-exact, max dev %g" % dev)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 @pytest.mark.parametrize("B,d,N", [(256, 7, 200), (64, 6, 500), (130, 3, 50), (65, 1, 20), (97, 8, 64),
                                    (40, 2, 33), (33, 4, 70), (50, 5, 101)])
 def test_solve_batch_matches_oracle(gpu, oracle, B, d, N, variant):
@@ -37,7 +37,7 @@ def test_solve_batch_matches_oracle(gpu, oracle, B, d, N, variant):
     _compare(got, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 def test_nonzero_boundary_velocities(gpu, oracle, variant):
     data = batch.make_synthetic_batch(128, 7, 100, seed=7)
     rng = np.random.default_rng(5)
@@ -64,7 +64,7 @@ def test_collocation_and_single_constraint(gpu, oracle):
     _compare(got, ref)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 4])
 @pytest.mark.parametrize("B,d,N,nway", [(9, 2, 1, 2), (17, 3, 2, 3), (33, 7, 3, 2), (64, 1, 5, 4), (1, 7, 200, 5),
                                         (31, 8, 7, 9), (257, 6, 33, 6)])
 def test_edge_shapes(gpu, oracle, B, d, N, nway, variant):
@@ -95,13 +95,17 @@ def test_empty_batch_and_bad_arguments(gpu):
 
 @pytest.mark.parametrize("B,d,N", [(200, 17, 40), (130, 24, 60), (70, 32, 30)])
 def test_dof_17_to_32_on_the_generic_kernel(gpu, oracle, B, d, N):
-    """The reference has no dof limit; 17..32 dof run on the generic lane-per-trajectory kernel (auto)."""
+    """The reference has no dof limit; 17..32 dof run on the generic lane-per-trajectory kernel and on the
+    one-trajectory-per-wave kernel (two / three row slots per lane; auto for these batch sizes)."""
     data = batch.make_synthetic_batch(B, d, N, seed=d)
     rng = np.random.default_rng(d)
     sd1 = np.where(rng.random(B) < 0.3, 0.1 * rng.random(B), 0.0)
     ref = oracle.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], None, sd1)
     got = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], None, sd1)
     _compare(got, ref)
+    for variant in (1, 4):
+        _compare(batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], None, sd1,
+                                   variant=variant), ref)
     X = batch.feasible_sets_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
     K = batch.controllable_sets_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], sd1, sd1)
     assert np.array_equal(K, ref["K"], equal_nan=True) and X.shape == K.shape
@@ -114,7 +118,7 @@ def test_wide_dof_and_long_splines(gpu, oracle, B, d, N, nway):
     coefficient table in global memory instead of LDS.  Both against the oracle, both families."""
     data = batch.make_synthetic_batch(B, d, N, seed=d * 100 + nway, n_waypoints=nway)
     ref = oracle.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
-    for variant in (1, 2):
+    for variant in (1, 2, 4):
         got = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], variant=variant)
         _compare(got, ref)
     strict = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], strict=True)
@@ -137,7 +141,7 @@ def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
     flags = (FLAG_VEL if vlim is not None else 0) | (FLAG_ACC if alim is not None else 0) | (FLAG_INTERP if interp else 0)
     args = (data["coef"], data["breaks"], data["grid"], vlim, alim, None, sd1, interp)
     lane = batch.solve_batch(*args, variant=1)
-    kws = [dict(variant=2), dict(variant=2, strict=True), dict()]
+    kws = [dict(variant=2), dict(variant=2, strict=True), dict(), dict(variant=4), dict(variant=4, strict=True)]
     if alim is not None and d <= 8:
         kws.append(dict(variant=3))  # the certified lane kernel: Interpolation and Collocation, velocity optional
     for kw in kws:

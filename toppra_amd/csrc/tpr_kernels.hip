@@ -15,6 +15,7 @@
 #include "tpr_lane.hip.inc"
 #include "tpr_group.hip.inc"
 #include "tpr_cert.hip.inc"
+#include "tpr_wave.hip.inc"
 #include "tpr_spline.hip.inc"
 #include "tpr_param.hip.inc"
 #include "tpr_robust.hip.inc"
@@ -139,6 +140,10 @@ tpr::BatchArgs stage_problem(const tpr_problem *p, Staging &S) {
 }
 
 constexpr size_t kMaxDynamicLds = 64 * 1024;
+#ifndef TPR_WAVE_AUTO_MAX_BATCH
+#define TPR_WAVE_AUTO_MAX_BATCH 5120  // auto: one wave per trajectory up to this many trajectories (4096: 0.86 vs 1.11 ms for
+                                      // family 2; 8192: 1.51 vs 1.31 -- tools/gpu_wave_check.py)
+#endif
 
 template <int D, int L>
 size_t group_lds_bytes(int nseg, int threads, bool table_in_lds) {
@@ -323,15 +328,55 @@ int dispatch_group_robust(const tpr::RobustArgs &P, hipStream_t stream) {
     return fail(TPR_E_UNSUPPORTED, "dof out of range");
 }
 
+// Family 4 (one trajectory per wave): every constraint set, every dof; grid, x box and K of the trajectory must
+// fit the dynamic LDS of a block (5 (N+1) doubles: N <= 1480; the spline table joins them when there is room).
+size_t wave_lds_bytes(const tpr::BatchArgs &A, bool table_in_lds) {
+    return tpr::wave_lds_doubles(A.N, A.nseg, A.d, table_in_lds) * sizeof(double);
+}
+bool wave_supported(const tpr::BatchArgs &A) {
+    return A.d >= 1 && A.d <= TPR_MAX_DOF && A.N >= 1 && A.nseg <= 65535 && wave_lds_bytes(A, false) <= kMaxDynamicLds;
+}
+
+int launch_wave(const tpr::BatchArgs &A, hipStream_t stream) {
+    const bool table = wave_lds_bytes(A, true) <= kMaxDynamicLds;
+    const size_t lds = wave_lds_bytes(A, table);
+    const int slots = (4 * A.d + 6 + 63) / 64;  // virtual rows per LP / 64 lanes
+    const dim3 grid(A.B), block(64);
+#define TPR_LAUNCH_WAVE(SS)                                                                                   \
+    do {                                                                                                      \
+        if (table) hipLaunchKernelGGL((tpr::wave_solve_kernel<SS, true>), grid, block, lds, stream, A);       \
+        else hipLaunchKernelGGL((tpr::wave_solve_kernel<SS, false>), grid, block, lds, stream, A);            \
+    } while (0)
+    switch (slots) {
+        case 1: TPR_LAUNCH_WAVE(1); break;
+        case 2: TPR_LAUNCH_WAVE(2); break;
+        case 3: TPR_LAUNCH_WAVE(3); break;
+        default: return fail(TPR_E_UNSUPPORTED, "variant 4: dof out of range");
+    }
+#undef TPR_LAUNCH_WAVE
+    return TPR_E_OK;
+}
+
+// Kernel family of a solve (tpr_problem.variant 0 = auto).
+int pick_variant(int requested, const tpr::BatchArgs &A) {
+    if (requested != 0) return requested;
+    // Batches that cannot fill the chip are bound by the latency of a trajectory's 3N sequential stage LPs: one
+    // wave per trajectory (family 4).  Family 3 finishes up to 65536 trajectories (one wave per SIMD) in one
+    // fixed-latency round, which beats family 2's throughput from about a quarter of that batch upward
+    // (tools/gpu_crossover.py); family 2 serves the strict mode and what is left.
+    if (wave_supported(A) && A.B <= TPR_WAVE_AUTO_MAX_BATCH) return 4;
+    if (cert_supported(A) && A.B >= 14336) return 3;
+    return group_supported(A) ? 2 : (wave_supported(A) ? 4 : 1);
+}
+
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
     if (A.B == 0) return TPR_E_OK;
-    int variant = p->variant;
-    // auto: family 3 finishes up to 65536 trajectories (one wave per SIMD) in one fixed-latency round,
-    // which beats family 2's throughput from about a quarter of that batch upward (tools/gpu_crossover.py:
-    // 12 288: 1.65 vs 1.63 ms, 16 384: 1.71 vs 1.64, 20 480: 2.17 vs 1.68); smaller batches spread better
-    // over the chip with family 2's 8 lanes per trajectory
-    if (variant == 0) variant = (cert_supported(A) && A.B >= 14336) ? 3 : (group_supported(A) ? 2 : 1);
+    const int variant = pick_variant(p->variant, A);
     switch (variant) {
+        case 4: {
+            if (!wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables (N <= 1480)");
+            return launch_wave(A, stream);
+        }
         case 3: {
             if (!cert_supported(A))
                 return fail(TPR_E_UNSUPPORTED, "variant 3 needs acceleration+interpolation, d <= 8, sd2/u/status outputs, default mode");
@@ -394,6 +439,62 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
     }
 }
 
+// Host-buffer calls on a handful of trajectories (the reference's own use: ONE trajectory per
+// compute_parameterization call) are all latency.  Instead of a dozen stream-ordered allocations and pageable copies
+// they go through one page-locked, device-mapped arena per calling thread: the inputs are packed into it by the CPU,
+// the kernel reads them over PCIe (every input is fetched once, by coalesced loads issued together) and writes its
+// outputs straight back into it; one launch, one stream synchronisation, two memcpy's on the host.
+constexpr int kNotSmall = 1;
+constexpr size_t kSmallCallBytes = 1 << 20;
+struct HostArena {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int device = -1;
+};
+thread_local HostArena g_arena;  // (never freed: a thread's exit may come after the runtime's own teardown)
+
+int solve_small_host_call(const tpr_problem *p, const tpr_result *r, hipStream_t stream, int device) {
+    const size_t B = (size_t)p->B, d = (size_t)p->d, nseg = (size_t)p->nseg, N = (size_t)p->N;
+    struct Piece { const void *src; void *dst; size_t bytes, off; };
+    Piece in[7] = {{p->coef, nullptr, B * 4 * nseg * d * 8, 0},
+                   {p->breaks, nullptr, ((p->flags & TPR_BREAKS_PER_TRAJ) ? B : 1) * (nseg + 1) * 8, 0},
+                   {p->grid, nullptr, ((p->flags & TPR_GRID_PER_TRAJ) ? B : 1) * (N + 1) * 8, 0},
+                   {p->vlim, nullptr, B * d * 16, 0}, {p->alim, nullptr, B * d * 16, 0},
+                   {p->sd_start, nullptr, B * 8, 0}, {p->sd_end, nullptr, B * 8, 0}};
+    Piece out[5] = {{nullptr, r->sd2, B * (N + 1) * 8, 0}, {nullptr, r->sd, B * (N + 1) * 8, 0}, {nullptr, r->u, B * N * 8, 0},
+                    {nullptr, r->K, B * (N + 1) * 16, 0}, {nullptr, r->status, B * 4, 0}};
+    size_t total = 0;
+    for (auto &q : in) { q.off = total; if (q.src) total += (q.bytes + 15) & ~(size_t)15; }
+    for (auto &q : out) { q.off = total; if (q.dst) total += (q.bytes + 15) & ~(size_t)15; }
+    if (total > kSmallCallBytes) return kNotSmall;
+    tpr::BatchArgs A{};
+    A.B = p->B; A.d = p->d; A.nseg = p->nseg; A.N = p->N; A.flags = p->flags;
+    A.sd2 = r->sd2; A.sd = r->sd; A.u = r->u; A.K = r->K; A.status = r->status;  // (what is asked for decides the family)
+    if (pick_variant(p->variant, A) != 4) return kNotSmall;  // the other families want workspaces: the general path
+    if (g_arena.cap < total || g_arena.device != device) {
+        if (g_arena.ptr) (void)hipHostFree(g_arena.ptr);
+        g_arena = HostArena{};
+        void *mem = nullptr;
+        const size_t cap = total > (size_t)(256 << 10) ? kSmallCallBytes : (size_t)(256 << 10);
+        if (hipHostMalloc(&mem, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return kNotSmall; }
+        g_arena.ptr = mem; g_arena.cap = cap; g_arena.device = device;
+    }
+    char *base = static_cast<char *>(g_arena.ptr);
+    for (auto &q : in) if (q.src) std::memcpy(base + q.off, q.src, q.bytes);
+    auto at = [&](const Piece &q) { return reinterpret_cast<double *>(base + q.off); };
+    A.coef = at(in[0]); A.breaks = at(in[1]); A.grid = at(in[2]);
+    A.vlim = in[3].src ? at(in[3]) : nullptr; A.alim = in[4].src ? at(in[4]) : nullptr;
+    A.sd_start = in[5].src ? at(in[5]) : nullptr; A.sd_end = in[6].src ? at(in[6]) : nullptr;
+    A.sd2 = out[0].dst ? at(out[0]) : nullptr; A.sd = out[1].dst ? at(out[1]) : nullptr;
+    A.u = out[2].dst ? at(out[2]) : nullptr; A.K = out[3].dst ? at(out[3]) : nullptr;
+    A.status = out[4].dst ? reinterpret_cast<int32_t *>(base + out[4].off) : nullptr;
+    if (int rc = launch_solve(p, A, stream)) return rc;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (auto &q : out) if (q.dst) std::memcpy(q.dst, base + q.off, q.bytes);
+    return TPR_E_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -445,6 +546,10 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
     if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    if (!(p->flags & TPR_DEVICE_PTRS) && p->B > 0) {
+        const int rc = solve_small_host_call(p, r, stream, scope.dev);
+        if (rc != kNotSmall) return rc;
+    }
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     const size_t B = (size_t)p->B, N = (size_t)p->N;
@@ -461,8 +566,18 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream_) {
         if (S.err == hipSuccess) S.owned.push_back(ws);
         return static_cast<double *>(ws);
     };
-    A.u = r->u ? S.out(r->u, B * N) : workspace(B * N);
-    A.K = r->K ? S.out(r->K, B * (N + 1) * 2) : workspace(B * (N + 1) * 2);
+    // (family 4 keeps K in LDS and skips what is not asked for: no workspace, no HBM traffic for it)
+    A.u = r->u ? S.out(r->u, B * N) : nullptr;
+    A.K = r->K ? S.out(r->K, B * (N + 1) * 2) : nullptr;
+    {
+        tpr::BatchArgs probe = A;  // the variant the call will take, with every output it could ask a workspace for
+        if (!probe.u) probe.u = reinterpret_cast<double *>(8);
+        if (!probe.K) probe.K = reinterpret_cast<double *>(8);
+        if (pick_variant(p->variant, probe) != 4) {
+            if (!A.u) A.u = workspace(B * N);
+            if (!A.K) A.K = workspace(B * (N + 1) * 2);
+        }
+    }
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (int rc = launch_solve(p, A, stream)) return rc;
     HIP_TRY(S.finish());
@@ -590,7 +705,7 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
     A.K = S.out(K, B * (N + 1) * 2);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (A.B > 0) {
-        if (group_supported(A) && A.N >= 1) {  // the backward scan of the fast kernels
+        if ((group_supported(A) || wave_supported(A)) && A.N >= 1) {  // the backward scan of the fast kernels
             A.sd_end = dmin;
             A.sd_end_hi = dmax;
             A.backward_only = 1;

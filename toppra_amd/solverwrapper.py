@@ -103,6 +103,7 @@ class hipSeidelWrapper(SolverWrapper):
         # warm-start state of the two LP "solvers", as in the reference object
         self._active = np.zeros((1, 4), dtype=np.int32)
         self._params = None  # device init is lazy: every compute entry calls _capi.init()
+        self._call_state = None  # persistent problem / result structures of `parameterization`
 
     @property
     def params(self):
@@ -128,9 +129,32 @@ class hipSeidelWrapper(SolverWrapper):
         return L[0], X[0]
 
     def parameterization(self, sd_start, sd_end):
-        out = batch.solve_batch(*self._args(), np.array([sd_start], dtype=np.float64),
-                                np.array([sd_end], dtype=np.float64), self._interp, want_sd=True)
-        return {k: v[0] for k, v in out.items()}
+        """One compute_parameterization: sd2, sd, u, K [views of per-instance buffers], status.  A single
+        trajectory is pure call latency, so the problem description, the result buffers and the ctypes
+        arguments are built once per instance; a call writes the two boundary velocities and makes one
+        library call (which takes its small-host-call path: csrc/tpr_kernels.hip)."""
+        st = self._call_state
+        if st is None:
+            sd0, sd1 = np.zeros(1), np.zeros(1)
+            p, keep = _capi.make_problem(*self._args(), sd0, sd1, self._interp)
+            N = self.N
+            out = {"sd2": np.empty((1, N + 1)), "sd": np.empty((1, N + 1)), "u": np.empty((1, N)),
+                   "K": np.empty((1, N + 1, 2)), "status": np.empty((1,), dtype=np.int32)}
+            r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out["sd"]), u=_capi.ptr(out["u"]),
+                                 K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
+            views = {k: v[0] for k, v in out.items() if k != "status"}
+            st = self._call_state = (sd0, sd1, C.byref(p), C.byref(r), _capi.load().tpr_solve_batch, views,
+                                     out["status"], (p, r, keep, out))
+        sd0, sd1, pref, rref, fn, views, status = st[:7]
+        sd0[0] = sd_start
+        sd1[0] = sd_end
+        _capi.init()
+        rc = fn(pref, rref, None)
+        if rc != 0:
+            _capi.check(rc)
+        res = dict(views)
+        res["status"] = int(status[0])
+        return res
 
     def parameterization_sd(self, sd_start, sd_end, desired_duration, atol=1e-5):
         out = batch.solve_desired_duration_batch(*self._args(), desired_duration,
