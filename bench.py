@@ -56,35 +56,122 @@ def pmc_traffic(B, d, N, kernel_ms):
             "bytes_per_launch_fetch_x2": pmc["hbm_bytes_per_launch_fetch_x2"],
             "gbps": pmc["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9,
             "kernel": pmc.get("kernel"), "valu_busy": pmc.get("valu_busy"), "avg_active_lanes": pmc.get("avg_active_lanes"),
+            "valu_wave_instructions_per_launch": pmc["counters"].get("SQ_INSTS_VALU"),
+            "salu_wave_instructions_per_launch": pmc["counters"].get("SQ_INSTS_SALU"),
+            "REPLAYED": "every field of this block is read from profiles/%s -- rocprofv3 --pmc passes of this same command "
+                        "(separate passes, no tracing), committed with the kernel they were taken on; they are NOT measured in "
+                        "this run (counters cannot be read from inside bench.py).  Measured in this run: kernel_ms, ms_per_step, "
+                        "value, roofline.achieved" % os.path.basename(path),
             "source": "profiles/%s (rocprofv3 --pmc, separate passes)" % os.path.basename(path)}
 
 
+# fp64 VALU issue peak: 256 CUs x 4 SIMDs x 16 lanes per cycle at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
+VALU_PEAK_LANE_INSTR = 256 * 4 * 16 * 2.4e9
+
+
+def compute_roofline(pmc, kernel_ms):
+    """What actually binds the fused kernel: vector-ALU instruction issue (SURVEY.md section 8(d) asks for it beside the
+    HBM figure).  Lane-instructions per second = VALU wave-instructions per launch (PMC pass, replayed from
+    profiles/) x 64 lanes / the kernel time measured in this run, against 16 lanes per SIMD and cycle."""
+    if not pmc or not pmc.get("valu_wave_instructions_per_launch"):
+        return None
+    n = pmc["valu_wave_instructions_per_launch"]
+    achieved = n * 64 / (kernel_ms * 1e-3)
+    return {"bound": "valu_issue", "achieved": achieved, "peak": VALU_PEAK_LANE_INSTR, "unit": "fp64-lane-instructions/s",
+            "frac": achieved / VALU_PEAK_LANE_INSTR,
+            "valu_wave_instructions_per_launch": n, "kernel_ms": kernel_ms,
+            "valu_busy_pmc": pmc.get("valu_busy"), "avg_active_lanes_pmc": pmc.get("avg_active_lanes"),
+            "instruction_count_source": pmc["source"] + " -- REPLAYED, not measured in this run; kernel_ms is this run's",
+            "note": "every lane-instruction of this kernel is an fp64 / integer VALU operation of a 64-wide wave (no MFMA: the "
+                    "path has no dense contraction); one wave per SIMD, so the issue rate is additionally capped by the "
+                    "single-wave issue interval (~5 cycles per instruction of any kind: profiles/r02_single_wave_issue_microbench.log)"}
+
+
 def cpu_baseline(data, target_seconds=12.0):
-    """The oracle (C port of the reference's seidel path, bit-exact with it) on the host cores,
-    on a bounded sample of the same workload."""
+    """The oracle (C port of the reference's seidel path, bit-exact with it) on the host cores, on a bounded
+    sample of the same workload: one thread, then one thread per physical core (bound), with the parallel
+    efficiency of the two.  Every worker thread reuses one arena for all of its trajectories
+    (oracle/seidel_oracle.c: a fresh wrapper per trajectory used to mean fresh zero pages from the C library,
+    which is what a 256-thread run then measured -- 7 % efficiency in round 2)."""
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        physical = os.cpu_count() or 1
+    logical = os.cpu_count() or physical
+    # What this process may actually use: its affinity mask and the CPU bandwidth of its cgroup (the GPU box hands the
+    # container 16 CPUs' worth of a 128-core host: more threads than that are throttled and scale NEGATIVELY --
+    # tools/cpu_scaling_probe.py: 16 threads 15.3x one thread, 128 threads 9.3x)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()
+            quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q = float(fh.read())
+                quota = None if q <= 0 else q / float(fp.read())
+        except (OSError, ValueError):
+            quota = None
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = logical
+    cores = max(1, min(physical, affinity, int(quota) if quota else physical))
+    os.environ.setdefault("OMP_PLACES", "cores")     # (read when libgomp is loaded, i.e. by the import below)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
     B = data["coef"].shape[0]
 
-    def run(n):
+    def run(n, threads):
         t0 = time.perf_counter()
-        orc.solve_batch(data["coef"][:n], data["breaks"], data["grid"], data["vlim"][:n],
-                        data["alim"][:n], nthreads=cores)
+        orc.solve_batch(data["coef"][:n], data["breaks"], data["grid"], data["vlim"][:n], data["alim"][:n], nthreads=threads)
         return time.perf_counter() - t0
 
+    # one thread: ~2 s
+    run(64, 1)
+    t = run(256, 1)
+    n1 = int(min(B, max(256, 256 * 2.0 / max(t, 1e-6))))
+    t1 = min(run(n1, 1), run(n1, 1))
+    single = n1 / t1
+    # one thread per physical core
+    run(min(B, 8 * cores), cores)
     n0 = min(B, 64 * cores)
-    run(min(B, 8 * cores))  # warm the library / thread pool
-    t = run(n0)
+    t = run(n0, cores)
     n = int(min(B, max(n0, n0 * 2.0 / max(t, 1e-6))))  # ~2 s per pass, repeated to the target
-    reps = 0
-    total = 0.0
+    reps, total, best = 0, 0.0, 1e30
     while total < target_seconds and reps < 64:
-        total += run(n)
+        dt = run(n, cores)
+        total += dt
+        best = min(best, dt)
         reps += 1
-    return {"value": n * reps / total, "unit": "trajectories/s", "cores": cores, "kind": "port",
+    allcore = n * reps / total
+    # BASELINE config 1 beside the GPU's latency figure: one trajectory, one thread
+    c1 = {}
+    for label, N in (("N100", 100), ("N289", 289)):
+        from toppra_amd import batch as tb
+        one = tb.make_synthetic_batch(1, 7, N, seed=9)
+        args = (one["coef"], one["breaks"], one["grid"], one["vlim"], one["alim"])
+        orc.solve_batch(*args, nthreads=1)
+        ts = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            orc.solve_batch(*args, nthreads=1)
+            ts.append(time.perf_counter() - t0)
+        c1[label + "_ms"] = float(np.median(ts) * 1e3)
+    return {"value": allcore, "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "single_thread": {"value": single, "unit": "trajectories/s", "sample": "%d trajectories" % n1},
+            "parallel_efficiency": allcore / (cores * single),
+            "best_pass": n / best,
+            "host": {"physical_cores": physical, "logical_cpus": logical, "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
+                     "note": "`cores` = threads used = min(physical cores, affinity, cgroup CPU quota): what the container may run at once"},
+            "thread_binding": "OMP_PLACES=%s OMP_PROC_BIND=%s" % (os.environ.get("OMP_PLACES"), os.environ.get("OMP_PROC_BIND")),
+            "config1_single_trajectory": dict(c1, note="oracle/seidel_oracle.c on ONE host thread, one 7-dof trajectory per call "
+                                              "(N = 100 / 289 gridpoints): what configs.C1_single_trajectory is up against"),
             "sample": "first %d trajectories of the rank-0 batch x %d passes (%.1f s), oracle/seidel_oracle.c "
-                      "(C restatement of the reference's seidel path, bit-exact with it) with OpenMP over "
-                      "%d threads" % (n, reps, total, cores),
+                      "(C restatement of the reference's seidel path, bit-exact with it) with OpenMP on %d threads (bound, one "
+                      "per core: every CPU this container is allowed); per-thread arenas" % (n, reps, total, cores),
             "reference_itself": {
                 "value": 180.0, "unit": "trajectories/s per core", "where": "build container, 1 core, Python+Cython seidel",
                 "note": "the reference cannot run on the GPU box: /root/reference is absent there and its sources may not be "
@@ -425,10 +512,12 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_traj * B,
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_trajectory": bytes_per_traj,
+                "traffic_source": (pmc["source"] + " -- REPLAYED from the committed profile, not measured in this run") if pmc else None,
                 "pmc": pmc,
                 "note": "the fused path is bound by fp64 VALU issue and, at one wave per SIMD, by its own dependency "
-                        "latencies -- not by HBM: DESIGN.md section 3.5",
+                        "latencies -- not by HBM: DESIGN.md section 3.5; see roofline_compute",
             },
+            "roofline_compute": compute_roofline(pmc, kernel_ms),
         }
         if not args.no_secondary and world == 1:
             line["tolerance_build"] = tolerance_probe(B, d, N, 20240924 + rank, out["sd2"].cpu().numpy(), out["status"].cpu().numpy())

@@ -45,6 +45,13 @@ extern "C" {
 #define TPR_BREAKS_PER_TRAJ 16
 #define TPR_GRID_PER_TRAJ 32
 /* bit 64 is reserved (it selected an approximate mode in round 1, retired: every path is bit-exact now) */
+/* sd_start / sd_end (and sdmin / sdmax of tpr_controllable_sets_batch) hold the SQUARED boundary velocities
+ * x = sd^2, squared by the caller.  The reference squares them with Python's `**` (reachability_algorithm.py:226,
+ * :262): libm pow() for Python floats, which is not correctly rounded (one ulp off sd * sd for ~0.08 % of the
+ * values), numpy's sd * sd for arrays.  Without the flag the device computes sd * sd; a caller that must reproduce
+ * the Python-float case squares in that very expression and sets the flag (toppra_amd.algorithm.TOPPRA does).
+ * Honoured by tpr_solve_batch, tpr_controllable_sets_batch, tpr_solve_desired_duration_batch.                  */
+#define TPR_BOUNDARY_SQUARED 256
 /* Force every stage LP through the full Seidel iteration (served by the rows-across-lanes kernels).
  * By default the fast kernels answer a backward LP from a verified optimal vertex -- found as "x on its
  * box bound, u on the tightest row" (lower bound) or as the previous stage's active pair, if need be
@@ -80,6 +87,15 @@ typedef struct tpr_problem {
     const double *alim;
     const double *sd_start;
     const double *sd_end;
+    int32_t *active; /* [B][4] = active_c_up[2], active_c_down[2] (may be NULL = a fresh object): the warm-start
+                        state of the reference's seidelWrapper OBJECT (cy_seidel_solverwrapper.pyx:526-527), which
+                        persists across the passes run on one instance and is also written by the forward pass's
+                        1-D path (:646-649).  Read at the start and updated at the end of tpr_solve_batch,
+                        tpr_controllable_sets_batch and tpr_feasible_sets_batch, so that a sequence of passes on one
+                        object (examples/plot_kinematics.py:48,72) returns the reference's bits.  Maintained by kernel
+                        family 4 (auto-selected when set); where that family cannot take the problem (N > 1480) or
+                        another variant is forced, the pass starts from a fresh object's state and leaves the array
+                        untouched.  The other entries ignore it (tpr_solve_stagewise_batch takes its own argument). */
 } tpr_problem;
 
 typedef struct tpr_result {
@@ -93,11 +109,13 @@ typedef struct tpr_result {
 } tpr_result;
 
 /* Library / device management.  tpr_init(device) verifies that `device` is a gfx950 GPU and makes it
- * the default device of host-pointer calls; it must succeed once before any other call and fails
- * (TPR_E_HIP / TPR_E_UNSUPPORTED) otherwise.  The calling thread's current HIP device is NOT changed:
- * every entry point runs on the device its data lives on -- the device of the pointers with
- * TPR_DEVICE_PTRS, the tpr_init device otherwise -- and restores the caller's device on return, so
- * the library is safe next to frameworks (torch) that move the per-thread current device.        */
+ * the default device of the CALLING THREAD's host-pointer calls (a thread that never called tpr_init
+ * uses the device of the process's last tpr_init); it must succeed once before any other call and
+ * fails (TPR_E_HIP / TPR_E_UNSUPPORTED) otherwise.  The calling thread's current HIP device is NOT
+ * changed: every entry point runs on the device its data lives on -- the device of the pointers with
+ * TPR_DEVICE_PTRS, the thread's tpr_init device otherwise -- and restores the caller's device on
+ * return, so the library is safe next to frameworks (torch) that move the per-thread current device,
+ * and threads working on different GPUs do not disturb each other.                                 */
 int tpr_init(int device);
 int tpr_device_count(void);
 const char *tpr_last_error(void);

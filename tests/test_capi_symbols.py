@@ -30,10 +30,17 @@ def test_header_symbols_exported():
 
 def test_struct_layout_matches_header():
     from toppra_amd import _capi
-    # 6 int32 then 7 pointers; 5 pointers
-    assert ctypes.sizeof(_capi.tpr_problem) == 6 * 4 + 7 * 8
+    # 6 int32 then 8 pointers (the last one: the wrapper object's warm-start state, r3); 5 pointers
+    assert ctypes.sizeof(_capi.tpr_problem) == 6 * 4 + 8 * 8
     assert ctypes.sizeof(_capi.tpr_result) == 5 * 8
     assert _capi.tpr_problem.coef.offset == 24
+    assert _capi.tpr_problem.active.offset == 24 + 7 * 8
+    # the header declares the same members in the same order
+    hdr = open(os.path.join(ROOT, "include", "toppra_hip.h")).read()
+    body = hdr[hdr.index("typedef struct tpr_problem {"):hdr.index("} tpr_problem;")]
+    order = [body.index(name) for name in ("B, d, nseg, N", "flags;", "variant;", "*coef;", "*breaks;", "*grid;", "*vlim;",
+                                           "*alim;", "*sd_start;", "*sd_end;", "*active;")]
+    assert order == sorted(order)
 
 
 def test_no_cpu_fallback():

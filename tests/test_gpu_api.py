@@ -215,3 +215,94 @@ def test_compute_reachable_sets_drop_in(gpu, oracle):
     fx = golden("reach_d5_N60")
     binst = ta.algorithm.BatchTOPPRA(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"])
     assert_same(binst.compute_reachable_sets(fx["sdmin"], fx["sdmax"]), fx["L"], "batch L")
+
+
+def _reuse_instance(fx, b):
+    from tests.helpers import path_from_tables
+    path = path_from_tables(fx["coef"][b], fx["breaks"])
+    scheme = ta.constraint.DiscretizationType(int(fx["scheme"][b]))
+    cons = [ta.constraint.JointVelocityConstraint(fx["vlim"][b]),
+            ta.constraint.JointAccelerationConstraint(fx["alim"][b], discretization_scheme=scheme)]
+    return ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"])
+
+
+def test_passes_chained_on_one_instance_match_the_reference(gpu):
+    """examples/plot_kinematics.py:48,72 run several passes on ONE algorithm instance; the reference's wrapper object
+    carries its warm-start state (active_c_up / active_c_down) from pass to pass, and the later passes pivot from
+    there.  tests/golden/reuse_d7_N100 holds compute_parameterization -> compute_feasible_sets ->
+    compute_controllable_sets -> compute_parameterization on one reference instance per trajectory (in 9 / 5 of the
+    24 the carried state changes bits of X / K against a fresh instance): reproduced bit for bit through the class,
+    whose wrapper threads the state through every pass (tpr_problem.active)."""
+    fx = golden("reuse_d7_N100")
+    B = fx["coef"].shape[0]
+    differs = 0
+    for b in range(B):
+        inst = _reuse_instance(fx, b)
+        sd0, sd1 = float(fx["sd_start"][b]), float(fx["sd_end"][b])
+        st_code = {0: "Ok", 1: "FailUncontrollable", 2: "ErrUnknown"}
+
+        def param(tag):
+            sdd, sd, _, K = inst.compute_parameterization(np.float64(sd0), np.float64(sd1), return_data=True)
+            assert inst.problem_data.return_code.name == st_code[int(fx["status" + tag][b])], (b, tag)
+            assert_same(K, fx["K" + tag][b], "K%s[%d]" % (tag, b))
+            if sd is not None:
+                assert_same(sd, fx["sd" + tag][b], "sd%s[%d]" % (tag, b))
+                assert_same(sdd, fx["u" + tag][b], "u%s[%d]" % (tag, b))
+        param("1")
+        assert_same(inst.compute_feasible_sets(), fx["X"][b], "X[%d]" % b)
+        assert_same(inst.compute_controllable_sets(np.float64(fx["sdmin"][b]), np.float64(fx["sdmax"][b])), fx["K2"][b], "K2[%d]" % b)
+        param("3")
+        # ... and a FRESH instance gives the fresh-instance bits
+        fresh = _reuse_instance(fx, b)
+        assert_same(fresh.compute_feasible_sets(), fx["X_fresh"][b], "X_fresh[%d]" % b)
+        differs += not np.array_equal(fx["X"][b], fx["X_fresh"][b], equal_nan=True)
+    assert differs >= 5  # the fixture does exercise the carried state
+
+
+def test_warm_start_state_through_the_batch_entries(gpu, oracle):
+    """tpr_problem.active on the batch entries: the same chain for a whole batch at once, against the oracle's
+    wrapper objects (pinned to the reference's by tests/test_oracle_vs_reference.py), states included."""
+    fx = golden("reuse_d7_N100")
+    keep = np.flatnonzero(fx["scheme"] == 1)
+    coef, vlim, alim = fx["coef"][keep], fx["vlim"][keep], fx["alim"][keep]
+    B = len(keep)
+    active = np.zeros((B, 4), dtype=np.int32)
+    out = batch.solve_batch(coef, fx["breaks"], fx["grid"], vlim, alim, fx["sd_start"][keep], fx["sd_end"][keep], active=active)
+    X = batch.feasible_sets_batch(coef, fx["breaks"], fx["grid"], vlim, alim, active=active)
+    K2 = batch.controllable_sets_batch(coef, fx["breaks"], fx["grid"], vlim, alim, fx["sdmin"][keep], fx["sdmax"][keep], active=active)
+    assert_same(out["K"], fx["K1"][keep], "K1")
+    assert_same(X, fx["X"][keep], "X")
+    assert_same(K2, fx["K2"][keep], "K2")
+    for j, b in enumerate(keep):
+        w = oracle.Wrapper(fx["coef"][b], fx["breaks"], fx["grid"], fx["vlim"][b], fx["alim"][b])
+        w.compute_parameterization(float(fx["sd_start"][b]), float(fx["sd_end"][b]))
+        w.compute_feasible_sets()
+        w.compute_controllable_sets(float(fx["sdmin"][b]), float(fx["sdmax"][b]))
+        assert np.array_equal(w.active(), active[j]), (b, w.active(), active[j])
+
+
+def test_boundary_velocities_squared_like_the_reference(gpu):
+    """`sd ** 2` on Python floats is libm's pow(sd, 2.0), one ulp off sd * sd for ~0.08 % of the doubles; the
+    reference squares its boundary velocities that way (reachability_algorithm.py:226,:262).  Every boundary
+    velocity of tests/golden/pow_boundary_d3_N40 is such a value: the class squares with the same expression and
+    hands x = sd^2 down (TPR_BOUNDARY_SQUARED), so K, sd and u are the reference's bits; squaring on the device
+    (what the array entries do, correctly for numpy inputs) would be off in K[N] of every trajectory."""
+    from tests.helpers import path_from_tables
+    fx = golden("pow_boundary_d3_N40")
+    B, N = fx["coef"].shape[0], len(fx["grid"]) - 1
+    assert all(float(v) ** 2 != float(v) * float(v) for v in fx["sd_end"])
+    for b in range(B):
+        path = path_from_tables(fx["coef"][b], fx["breaks"])
+        cons = [ta.constraint.JointVelocityConstraint(fx["vlim"][b]), ta.constraint.JointAccelerationConstraint(fx["alim"][b])]
+        inst = ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"])
+        sdd, sd, _, K = inst.compute_parameterization(float(fx["sd_start"][b]), float(fx["sd_end"][b]), return_data=True)
+        assert_same(K, fx["K"][b], "K[%d]" % b)
+        if int(fx["status"][b]) == 0:
+            assert_same(sd, fx["sd"][b], "sd[%d]" % b)
+            assert_same(sdd, fx["u"][b], "u[%d]" % b)
+        else:
+            assert sd is None
+        fresh = ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"])
+        assert_same(fresh.compute_controllable_sets(float(fx["sdmin"][b]), float(fx["sdmax"][b])), fx["Kc"][b], "Kc[%d]" % b)
+    dev = batch.solve_batch(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"], fx["sd_start"], fx["sd_end"])
+    assert (dev["K"][:, N, 0] != fx["K"][:, N, 0]).all()  # sd * sd on the device: the other rounding of the same square

@@ -87,3 +87,26 @@ def test_spline_fit_beyond_64_points(gpu):
         for b in (0, 5):
             want = CubicSpline(knots, way[b], bc_type=bc).c
             assert np.array_equal(coef[b], want) or np.max(np.abs(coef[b] - want)) <= 1e-9 * np.max(np.abs(want)), (m, bc)
+
+
+@pytest.mark.parametrize("kind", ["ParametrizeSpline", "ParametrizeConstAccel"])
+def test_failed_trajectories_have_nan_durations(gpu, kind):
+    """A batch with trajectories that cannot be parameterized (uncontrollable start velocity): their status is
+    non-zero and their duration is NaN -- the reference returns None for them -- for both parametrizers (the spline
+    one used to report 5 N seconds: every NaN velocity fell into the "standing stretch" rule); the others are
+    unaffected by their neighbours."""
+    B, d, N = 48, 6, 70
+    data = batch.make_synthetic_batch(B, d, N, seed=77)
+    sd0 = np.zeros(B)
+    sd0[::5] = 50.0  # far outside the controllable set at s = 0
+    inst = ta.algorithm.BatchTOPPRA(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    traj = inst.compute_trajectory(sd0, None, parametrizer=kind)
+    status, dur = np.asarray(traj.status), np.asarray(traj.duration)
+    assert (status[::5] == 1).all() and (np.delete(status, np.s_[::5]) == 0).all()
+    assert np.isnan(dur[status != 0]).all() and np.isfinite(dur[status == 0]).all() and (dur[status == 0] > 0).all()
+    good = inst.compute_trajectory(None, None, parametrizer=kind)
+    ok = np.flatnonzero(status == 0)
+    assert np.array_equal(np.asarray(good.duration)[ok], dur[ok])
+    if kind == "ParametrizeSpline":
+        kt = np.asarray(traj._sp["knot_times"])
+        assert np.isnan(kt[status != 0][:, 1:]).all()  # NaN time stamps, not a 5 s-per-gridpoint fiction

@@ -104,3 +104,25 @@ def test_oracle_reachable_sets_vs_reference_fixture(oracle, name):
         L, X = w.compute_reachable_sets(float(fx["sdmin"][b]), float(fx["sdmax"][b]))
         assert_same(L, fx["L"][b], "L[%d]" % b)
         assert_same(X, fx["X"][b], "X[%d]" % b)
+
+
+def test_oracle_wrapper_state_across_passes(oracle):
+    """The oracle's wrapper object carries active_c_up / active_c_down across passes like the reference's: the chain
+    compute_parameterization -> compute_feasible_sets -> compute_controllable_sets -> compute_parameterization of
+    tests/golden/reuse_d7_N100 (ONE reference instance per trajectory), bit for bit."""
+    from oracle.oracle import FLAG_ACC, FLAG_INTERP, FLAG_VEL
+    fx = golden("reuse_d7_N100")
+    for b in range(fx["coef"].shape[0]):
+        flags = FLAG_VEL | FLAG_ACC | (FLAG_INTERP if int(fx["scheme"][b]) == 1 else 0)
+        w = oracle.Wrapper(fx["coef"][b], fx["breaks"], fx["grid"], fx["vlim"][b], fx["alim"][b], flags=flags)
+        for tag in ("1", None, "3"):
+            if tag is None:
+                assert np.array_equal(w.compute_feasible_sets(), fx["X"][b], equal_nan=True), b
+                assert np.array_equal(w.compute_controllable_sets(float(fx["sdmin"][b]), float(fx["sdmax"][b])), fx["K2"][b],
+                                      equal_nan=True), b
+                continue
+            st, sdd, sd, xs, K = w.compute_parameterization(float(fx["sd_start"][b]), float(fx["sd_end"][b]))
+            assert st == int(fx["status" + tag][b]), (b, tag)
+            assert np.array_equal(K, fx["K" + tag][b], equal_nan=True), (b, tag)
+            if st == 0:
+                assert np.array_equal(sd, fx["sd" + tag][b]) and np.array_equal(sdd, fx["u" + tag][b]), (b, tag)

@@ -328,8 +328,108 @@ def reachable_fixture(name="reach_d5_N60", B=24, d=5, N=60, seed=41, scheme=1):
     print(name, ": trajectories with a NaN stage", int(np.isnan(out["L"]).any(axis=(1, 2)).sum()), "of", B)
 
 
+def reuse_fixture(name="reuse_d7_N100", B=24, d=7, N=100, seed=51):
+    """Passes chained on ONE reference instance, in the order of examples/plot_kinematics.py (:48 compute_trajectory,
+    :72 compute_feasible_sets) and on: compute_parameterization -> compute_feasible_sets ->
+    compute_controllable_sets -> compute_parameterization again.  The wrapper object's warm-start state
+    (active_c_up / active_c_down, cy_seidel_solverwrapper.pyx:526-527, also written by the forward pass's 1-D path
+    :646-649) carries over from pass to pass, so every pass after the first pivots from where the previous one left
+    off.  The same passes on FRESH instances are stored beside them (X_fresh, K2_fresh): where they differ, the
+    carried state decided the bits."""
+    rng = np.random.default_rng(seed)
+    knots = np.linspace(0, 1, 5)
+    grid = np.concatenate([[0.0], np.sort(rng.random(N - 1)), [1.0]])
+    grid = 0.6 * grid + 0.4 * np.linspace(0, 1, N + 1)
+    keys = ("coef", "vlim", "alim", "sd_start", "sd_end", "sdmin", "sdmax", "scheme", "K1", "sd1", "u1", "status1", "X",
+            "K2", "K3", "sd3", "u3", "status3", "X_fresh", "K2_fresh")
+    recs = {k: [] for k in keys}
+    for b in range(B):
+        way = rng.standard_normal((5, d)) * (1.0 if b % 6 else 10.0 ** rng.uniform(-3, 0))
+        vmax = 10 + 20 * rng.random(d); amax = 10 + 2 * rng.random(d)
+        vl, al = np.stack([-vmax, vmax], 1), np.stack([-amax, amax], 1)
+        scheme = 0 if b % 4 == 3 else 1
+        sd0 = 0.0 if b % 3 else 0.1 * rng.random()
+        sd1 = 0.0 if b % 2 else 0.2 * rng.random()
+        sdmin = 0.0 if b % 5 else 0.1 * rng.random()
+        sdmax = sdmin + (0.0 if b % 2 else 0.3 * rng.random())
+        path = ta.SplineInterpolator(knots, way)
+        mk = lambda: algo.TOPPRA([constraint.JointVelocityConstraint(vl),
+                                  constraint.JointAccelerationConstraint(al, discretization_scheme=scheme)],
+                                 path, gridpoints=grid, solver_wrapper="seidel")
+        inst = mk()
+
+        def param(i):
+            sdd, sd, _, K = i.compute_parameterization(sd0, sd1, return_data=True)
+            st = STATUS[i.problem_data.return_code]
+            if sd is None:
+                sd, sdd = np.full(N + 1, np.nan), np.full(N, np.nan)
+            return K, sd, sdd, st
+
+        K1, s1, u1, st1 = param(inst)
+        X = inst.compute_feasible_sets()
+        K2 = inst.compute_controllable_sets(sdmin, sdmax)
+        K3, s3, u3, st3 = param(inst)
+        Xf = mk().compute_feasible_sets()
+        K2f = mk().compute_controllable_sets(sdmin, sdmax)
+        for k, v in zip(keys, (np.asarray(path.cspl.c), vl, al, sd0, sd1, sdmin, sdmax, scheme, K1, s1, u1, st1, X, K2, K3, s3, u3,
+                               st3, Xf, K2f)):
+            recs[k].append(v)
+    out = {k: np.array(v) for k, v in recs.items()}
+    out.update(breaks=np.asarray(path.cspl.x), grid=grid)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    same = lambda a, b: np.array([np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b)])
+    print(name, ": carried state changes bits of X in", int((~same(out["X"], out["X_fresh"])).sum()), ", of K2 in",
+          int((~same(out["K2"], out["K2_fresh"])).sum()), ", of the second parameterization in",
+          int((~(same(out["sd3"], out["sd1"]) & same(out["K3"], out["K1"]) & same(out["u3"], out["u1"]))).sum()), "of", B)
+
+
+def pow_fixture(name="pow_boundary_d3_N40", B=16, d=3, N=40, seed=61):
+    """Boundary velocities whose square the reference gets from libm: `sd ** 2` on Python floats is pow(sd, 2.0),
+    which is NOT sd * sd for ~0.08 % of the doubles (one ulp).  Every sd_start / sd_end here is such a value, passed
+    as a Python float, and the controllable-set call gets such sdmin / sdmax: K[N], K's lower rows near the end, and
+    xs[0] carry the difference."""
+    rng = np.random.default_rng(seed)
+
+    def odd_square(lo, hi):
+        while True:
+            x = float(rng.uniform(lo, hi))
+            if x ** 2 != x * x:
+                return x
+
+    knots = np.linspace(0, 1, 5)
+    grid = np.linspace(0, 1, N + 1)
+    keys = ("coef", "vlim", "alim", "sd_start", "sd_end", "sdmin", "sdmax", "K", "sd", "u", "status", "Kc")
+    recs = {k: [] for k in keys}
+    for b in range(B):
+        way = rng.standard_normal((5, d))
+        vmax = 10 + 20 * rng.random(d); amax = 10 + 2 * rng.random(d)
+        vl, al = np.stack([-vmax, vmax], 1), np.stack([-amax, amax], 1)
+        sd0, sd1 = odd_square(0.01, 0.3), odd_square(0.01, 0.3)
+        sdmin = odd_square(0.0, 0.1)
+        sdmax = odd_square(sdmin, sdmin + 0.2)
+        path = ta.SplineInterpolator(knots, way)
+        cons = [constraint.JointVelocityConstraint(vl), constraint.JointAccelerationConstraint(al)]
+        inst = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        sdd, sd, _, K = inst.compute_parameterization(sd0, sd1, return_data=True)
+        st = STATUS[inst.problem_data.return_code]
+        if sd is None:
+            sd, sdd = np.full(N + 1, np.nan), np.full(N, np.nan)
+        Kc = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_controllable_sets(sdmin, sdmax)
+        for k, v in zip(keys, (np.asarray(path.cspl.c), vl, al, sd0, sd1, sdmin, sdmax, K, sd, sdd, st, Kc)):
+            recs[k].append(v)
+    out = {k: np.array(v) for k, v in recs.items()}
+    out.update(breaks=np.asarray(path.cspl.x), grid=grid)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, ": ok", int((out["status"] == 0).sum()), "of", B, "; K[N] differs from sd_end * sd_end in",
+          int((out["K"][:, N, 0] != out["sd_end"] * out["sd_end"]).sum()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--reuse-only" in sys.argv:
+        reuse_fixture()
+        pow_fixture()
+        raise SystemExit(0)
     if "--reachable-only" in sys.argv:
         reachable_fixture()
         reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)
@@ -355,3 +455,5 @@ if __name__ == "__main__":
     batch_fixture("batch_d16_N30", 4, 16, 30, seed=15)
     reachable_fixture()
     reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)
+    reuse_fixture()
+    pow_fixture()

@@ -21,6 +21,7 @@ DEVICE_PTRS = 8
 BREAKS_PER_TRAJ = 16
 GRID_PER_TRAJ = 32
 STRICT_SEIDEL = 128
+BOUNDARY_SQUARED = 256
 
 STATUS_OK, STATUS_FAIL_UNCONTROLLABLE, STATUS_ERR_UNKNOWN = 0, 1, 2
 
@@ -37,7 +38,7 @@ class tpr_problem(C.Structure):
                 ("flags", C.c_int32), ("variant", C.c_int32),
                 ("coef", C.c_void_p), ("breaks", C.c_void_p), ("grid", C.c_void_p),
                 ("vlim", C.c_void_p), ("alim", C.c_void_p),
-                ("sd_start", C.c_void_p), ("sd_end", C.c_void_p)]
+                ("sd_start", C.c_void_p), ("sd_end", C.c_void_p), ("active", C.c_void_p)]
 
 
 class tpr_result(C.Structure):
@@ -138,11 +139,11 @@ def check(rc):
 
 
 def init(device=None):
-    """Select the HIP device for the calling thread; raises ToppraHipError when no gfx950 device is
-    usable.  HIP's current device is per thread and torch moves it (``torch.cuda.set_device``, device
-    contexts), so this is called on EVERY entry with the device the call's tensors live on -- it is one
-    ``hipSetDevice`` plus, the first time a device is seen, the gfx950 check.  ``device=None``: the
-    device of the last call, or LOCAL_RANK on the first."""
+    """Make ``device`` the default device of the calling thread's host-pointer calls; raises ToppraHipError when no
+    gfx950 device is usable.  The library never moves HIP's current device for its caller: every entry point scopes
+    itself to the device its data lives on (the device of the pointers, or this default for host arrays) and puts
+    the caller's device back.  Called on every entry -- it is one table look-up plus, the first time a device is
+    seen, the gfx950 check.  ``device=None``: the device of the last call, or LOCAL_RANK on the first."""
     global _inited_device
     L = load()
     if device is None:
@@ -212,12 +213,13 @@ def per_traj_vector(name, arr, B, like):
 
 
 def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
-                 variant=0, keep=None, strict=False):
+                 variant=0, keep=None, strict=False, active=None, squared=False):
     """Build a tpr_problem from arrays (all numpy or all torch-CUDA).  `keep` collects the
     converted arrays so they outlive the call.  Shapes and dtypes are validated here -- the C-ABI
     takes raw pointers and sizes, so a short or mistyped array would be read out of bounds:
     coef [B,4,nseg,d]; breaks [nseg+1] or [B,nseg+1]; grid [N+1] or [B,N+1] (strictly increasing);
-    vlim/alim [B,d,2]; sd_start/sd_end scalars or [B].  Device tensors must be float64 on coef's device."""
+    vlim/alim [B,d,2]; sd_start/sd_end scalars or [B]; active [B,4] int32 (in/out).  Device tensors must be float64
+    on coef's device."""
     dev = is_torch_cuda(coef)
     keep = keep if keep is not None else []
     if dev:
@@ -246,7 +248,7 @@ def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, int
         raise ValueError("grid needs at least two gridpoints")
     if not dev and not np.all(np.diff(grid, axis=-1) > 0):  # device grids are the caller's responsibility
         raise ValueError("grid must be strictly increasing")
-    flags = (DEVICE_PTRS if dev else 0) | (STRICT_SEIDEL if strict else 0)
+    flags = (DEVICE_PTRS if dev else 0) | (STRICT_SEIDEL if strict else 0) | (BOUNDARY_SQUARED if squared else 0)
     if breaks.ndim == 2:
         flags |= BREAKS_PER_TRAJ
     if grid.ndim == 2:
@@ -271,5 +273,16 @@ def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, int
             arr = _per_traj(name, arr, B, coef, dev)
             keep.append(arr)
             setattr(p, name, ptr(arr))
+    if active is not None:  # [B, 4] int32 warm-start state of the reference's wrapper object, updated in place
+        if dev:
+            import torch
+            if not (hasattr(active, "is_cuda") and active.is_cuda) or active.device != coef.device or \
+                    active.dtype != torch.int32 or tuple(active.shape) != (B, 4) or not active.is_contiguous():
+                raise ValueError("active must be a contiguous int32 tensor [B, 4] on coef's device")
+        elif not (isinstance(active, np.ndarray) and active.dtype == np.int32 and active.shape == (B, 4)
+                  and active.flags["C_CONTIGUOUS"]):
+            raise ValueError("active must be a C-contiguous int32 array [B, 4] (it is updated in place)")
+        keep.append(active)
+        p.active = ptr(active)
     p.flags = flags
     return p, keep

@@ -310,12 +310,18 @@ class BatchTrajectory(object):
     @property
     def duration(self):
         """[B] seconds (NaN where the parameterization failed)."""
+        status = self.status
         if self.kind == "spline":
             tk, cnt = self._sp["knot_times"], self._sp["counts"]
             if hasattr(tk, "gather"):  # torch
-                return tk.gather(1, (cnt.long() - 1).clamp(min=0)[:, None])[:, 0]
-            return tk[np.arange(tk.shape[0]), np.maximum(cnt - 1, 0)]
-        return self._ts[:, -1]
+                dur = tk.gather(1, (cnt.long() - 1).clamp(min=0)[:, None])[:, 0]
+                return dur.masked_fill(status.to(dur.device) != 0, float("nan"))
+            dur = tk[np.arange(tk.shape[0]), np.maximum(cnt - 1, 0)]
+        else:
+            dur = self._ts[:, -1]
+            if hasattr(dur, "masked_fill"):
+                return dur.masked_fill(status.to(dur.device) != 0, float("nan"))
+        return np.where(np.asarray(status) != 0, np.nan, dur)
 
     def __call__(self, times, order=0):
         if self.kind == "spline":

@@ -49,14 +49,17 @@ def _empty(like, shape, dtype="f64"):
 
 def _prepare(coef):
     if _capi.is_torch_cuda(coef):
-        dev = coef.device.index if coef.device.index is not None else 0
+        dev = coef.device.index
+        if dev is None:
+            import torch
+            dev = torch.cuda.current_device()
         _capi.init(dev)
     else:
         _capi.init()
 
 
 def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
-                want_sd=False, variant=0, strict=False, want_K=True, want_u=True):
+                want_sd=False, variant=0, strict=False, want_K=True, want_u=True, active=None):
     """compute_parameterization for B trajectories.
 
     Returns dict(sd2[B,N+1], u[B,N], K[B,N+1,2], status[B] (+ sd[B,N+1] if want_sd)); failed
@@ -66,10 +69,13 @@ def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, inte
     needs neither.
 
     ``strict=True`` (TPR_STRICT_SEIDEL) runs every stage LP through the reference's full Seidel
-    iteration instead of answering it from a certified optimal vertex (same bits, slower)."""
+    iteration instead of answering it from a certified optimal vertex (same bits, slower).
+
+    ``active`` [B, 4] int32 (in/out): the warm-start state ``active_c_up[2], active_c_down[2]`` of the
+    reference's wrapper object, for sequences of passes on one instance (``None`` = a fresh instance)."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
-                                 variant, strict=strict)
+                                 variant, strict=strict, active=active)
     B, N = p.B, p.N
     out = {"sd2": _empty(coef, (B, N + 1)), "status": _empty(coef, (B,), "i32")}
     if want_u:
@@ -139,10 +145,11 @@ def solve_batch_timed(coef, breaks, grid, vlim, alim, out, reps, sd_start=None, 
     return float(ms.value)
 
 
-def controllable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpolation=True):
-    """compute_controllable_sets(sdmin, sdmax) for B trajectories -> K[B,N+1,2]."""
+def controllable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpolation=True, active=None, squared=False):
+    """compute_controllable_sets(sdmin, sdmax) for B trajectories -> K[B,N+1,2] (``active``: see solve_batch;
+    ``squared``: sdmin / sdmax already hold sd^2 -- TPR_BOUNDARY_SQUARED)."""
     _prepare(coef)
-    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation, active=active, squared=squared)
     sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, coef)
     sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, coef)
     K = _empty(coef, (p.B, p.N + 1, 2))
@@ -165,10 +172,10 @@ def reachable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpola
     return (L, X) if want_X else L
 
 
-def feasible_sets_batch(coef, breaks, grid, vlim, alim, interpolation=True):
-    """compute_feasible_sets for B trajectories -> X[B,N+1,2]."""
+def feasible_sets_batch(coef, breaks, grid, vlim, alim, interpolation=True, active=None):
+    """compute_feasible_sets for B trajectories -> X[B,N+1,2] (``active``: see solve_batch)."""
     _prepare(coef)
-    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation, active=active)
     X = _empty(coef, (p.B, p.N + 1, 2))
     _capi.check(_capi.load().tpr_feasible_sets_batch(C.byref(p), _capi.ptr(X), _stream_ptr(coef)))
     return X
@@ -274,6 +281,11 @@ def ppoly_eval_batch(coef, breaks, times, order=0, counts=None):
             _capi.check_tensor(name, t, coef)
         coef, breaks, times = coef.contiguous(), breaks.contiguous(), times.contiguous()
         if counts is not None:
+            import torch
+            if not (hasattr(counts, "is_cuda") and counts.is_cuda) or counts.device != coef.device:
+                raise ValueError("counts must live on %s like coef" % (coef.device,))
+            if counts.dtype != torch.int32:  # the kernel reads raw int32: another integer type is converted, not reinterpreted
+                counts = counts.to(torch.int32)
             counts = counts.contiguous()
     else:
         coef, breaks, times = _capi.f64(coef), _capi.f64(breaks), _capi.f64(times)

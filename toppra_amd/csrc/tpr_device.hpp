@@ -28,6 +28,13 @@ constexpr float kJvelMaxSd = 1e8f;     // toppra/_CythonUtils.pyx:14 (a C float 
 
 __device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
 
+// x = sd^2 of a boundary path velocity.  The reference squares with Python's `**` (reachability_algorithm.py:226,
+// :262-266), i.e. libm pow() for Python floats -- NOT correctly rounded: it differs from sd * sd by one ulp for
+// about 0.08 % of the values -- and numpy's square (sd * sd) for numpy scalars and arrays.  A caller that has
+// squared the velocities itself, in the reference's own expression, says so with TPR_BOUNDARY_SQUARED (the drop-in
+// class does); otherwise the device squares them (exact for arrays, which is what the batch entries take).
+__device__ __forceinline__ double boundary_x(int flags, double v) { return (flags & TPR_BOUNDARY_SQUARED) ? v : v * v; }
+
 // One trajectory's read-only inputs.
 struct Traj {
     const double *coef;    // [4][nseg][d]

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,8 +24,14 @@
 namespace {
 
 thread_local std::string g_err;
-int g_device = -1;             // default device of host-pointer calls (last successful tpr_init)
-bool g_checked[64] = {false};  // devices already verified to be gfx950
+// Default device of host-pointer calls: the calling THREAD's last successful tpr_init, else the process's (a thread
+// that never called tpr_init inherits what another one selected).  Both, and the table of verified devices, may be
+// touched by several threads working on different GPUs.
+std::atomic<int> g_process_device{-1};
+thread_local int t_device = -1;
+std::atomic<bool> g_checked[64];  // devices already verified to be gfx950
+inline int default_device() { return t_device >= 0 ? t_device : g_process_device.load(std::memory_order_relaxed); }
+#define g_device default_device()
 
 // HIP's current device is per thread and other libraries (torch) move it.  Every entry point runs on
 // the device its data lives on -- the device of the pointers with TPR_DEVICE_PTRS, the tpr_init()
@@ -360,6 +367,7 @@ int launch_wave(const tpr::BatchArgs &A, hipStream_t stream) {
 // Kernel family of a solve (tpr_problem.variant 0 = auto).
 int pick_variant(int requested, const tpr::BatchArgs &A) {
     if (requested != 0) return requested;
+    if (A.active && wave_supported(A)) return 4;  // the wrapper object's warm-start state in / out: family 4 maintains it
     // Batches that cannot fill the chip are bound by the latency of a trajectory's 3N sequential stage LPs: one
     // wave per trajectory (family 4).  Family 3 finishes up to 65536 trajectories (one wave per SIMD) in one
     // fixed-latency round, which beats family 2's throughput from about a quarter of that batch upward
@@ -461,8 +469,9 @@ int solve_small_host_call(const tpr_problem *p, const tpr_result *r, hipStream_t
                    {p->grid, nullptr, ((p->flags & TPR_GRID_PER_TRAJ) ? B : 1) * (N + 1) * 8, 0},
                    {p->vlim, nullptr, B * d * 16, 0}, {p->alim, nullptr, B * d * 16, 0},
                    {p->sd_start, nullptr, B * 8, 0}, {p->sd_end, nullptr, B * 8, 0}};
-    Piece out[5] = {{nullptr, r->sd2, B * (N + 1) * 8, 0}, {nullptr, r->sd, B * (N + 1) * 8, 0}, {nullptr, r->u, B * N * 8, 0},
-                    {nullptr, r->K, B * (N + 1) * 16, 0}, {nullptr, r->status, B * 4, 0}};
+    Piece out[6] = {{nullptr, r->sd2, B * (N + 1) * 8, 0}, {nullptr, r->sd, B * (N + 1) * 8, 0}, {nullptr, r->u, B * N * 8, 0},
+                    {nullptr, r->K, B * (N + 1) * 16, 0}, {nullptr, r->status, B * 4, 0},
+                    {p->active, p->active, B * 16, 0}};  // (in and out)
     size_t total = 0;
     for (auto &q : in) { q.off = total; if (q.src) total += (q.bytes + 15) & ~(size_t)15; }
     for (auto &q : out) { q.off = total; if (q.dst) total += (q.bytes + 15) & ~(size_t)15; }
@@ -470,6 +479,7 @@ int solve_small_host_call(const tpr_problem *p, const tpr_result *r, hipStream_t
     tpr::BatchArgs A{};
     A.B = p->B; A.d = p->d; A.nseg = p->nseg; A.N = p->N; A.flags = p->flags;
     A.sd2 = r->sd2; A.sd = r->sd; A.u = r->u; A.K = r->K; A.status = r->status;  // (what is asked for decides the family)
+    A.active = p->active;
     if (pick_variant(p->variant, A) != 4) return kNotSmall;  // the other families want workspaces: the general path
     if (g_arena.cap < total || g_arena.device != device) {
         if (g_arena.ptr) (void)hipHostFree(g_arena.ptr);
@@ -481,6 +491,7 @@ int solve_small_host_call(const tpr_problem *p, const tpr_result *r, hipStream_t
     }
     char *base = static_cast<char *>(g_arena.ptr);
     for (auto &q : in) if (q.src) std::memcpy(base + q.off, q.src, q.bytes);
+    if (out[5].src) std::memcpy(base + out[5].off, out[5].src, out[5].bytes);
     auto at = [&](const Piece &q) { return reinterpret_cast<double *>(base + q.off); };
     A.coef = at(in[0]); A.breaks = at(in[1]); A.grid = at(in[2]);
     A.vlim = in[3].src ? at(in[3]) : nullptr; A.alim = in[4].src ? at(in[4]) : nullptr;
@@ -488,6 +499,7 @@ int solve_small_host_call(const tpr_problem *p, const tpr_result *r, hipStream_t
     A.sd2 = out[0].dst ? at(out[0]) : nullptr; A.sd = out[1].dst ? at(out[1]) : nullptr;
     A.u = out[2].dst ? at(out[2]) : nullptr; A.K = out[3].dst ? at(out[3]) : nullptr;
     A.status = out[4].dst ? reinterpret_cast<int32_t *>(base + out[4].off) : nullptr;
+    A.active = out[5].dst ? reinterpret_cast<int32_t *>(base + out[5].off) : nullptr;
     if (int rc = launch_solve(p, A, stream)) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
@@ -514,14 +526,15 @@ int tpr_init(int device) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return fail(TPR_E_HIP, "no HIP device visible");
     if (device < 0 || device >= n || device >= 64) return fail(TPR_E_BADARG, "device index out of range");
-    if (!g_checked[device]) {
+    if (!g_checked[device].load(std::memory_order_acquire)) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(TPR_E_UNSUPPORTED, std::string("this library is built for gfx950 only, found ") + prop.gcnArchName);
-        g_checked[device] = true;
+        g_checked[device].store(true, std::memory_order_release);
     }
-    g_device = device;  // the caller's current device is left alone: every entry scopes its own (DeviceScope)
+    t_device = device;  // the caller's current device is left alone: every entry scopes its own (DeviceScope)
+    g_process_device.store(device, std::memory_order_relaxed);
     return TPR_E_OK;
 }
 
@@ -553,6 +566,7 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream_) {
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     const size_t B = (size_t)p->B, N = (size_t)p->N;
+    A.active = S.out(p->active, B * 4, true);  // the wrapper object's warm-start state, in / out
     A.sd2 = S.out(r->sd2, B * (N + 1));
     A.sd = S.out(r->sd, B * (N + 1));
     A.status = S.out(r->status, B);
@@ -703,6 +717,7 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
     const size_t B = (size_t)p->B, N = (size_t)p->N;
     const double *dmin = S.in(sdmin, B), *dmax = S.in(sdmax, B);
     A.K = S.out(K, B * (N + 1) * 2);
+    A.active = S.out(p->active, B * 4, true);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (A.B > 0) {
         if ((group_supported(A) || wave_supported(A)) && A.N >= 1) {  // the backward scan of the fast kernels
@@ -754,9 +769,15 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
     Staging S(p->flags & TPR_DEVICE_PTRS, stream);
     tpr::BatchArgs A = stage_problem(p, S);
     double *dX = S.out(X, (size_t)p->B * (p->N + 1) * 2);
+    A.active = S.out(p->active, (size_t)p->B * 4, true);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (A.B > 0) {
-        if (group_supported(A)) {
+        if (wave_supported(A) && (A.active || A.B <= 64 || !group_supported(A))) {
+            // one trajectory per wave: a handful of trajectories (latency), 17..32 dof, or the wrapper object's
+            // warm-start state in / out
+            A.feasible_X = dX;
+            if (int rc = launch_wave(A, stream)) return rc;
+        } else if (group_supported(A)) {
             if (int rc = dispatch_group_feasible(A, dX, stream)) return rc;
         } else {
             hipLaunchKernelGGL(tpr::lane_feasible_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dX);

@@ -97,18 +97,19 @@ def propose_gridpoints(path, max_err_threshold=1e-4, max_iteration=100, max_seg_
     there are ``min_nb_points`` points.  One vectorised pass over all segments per refinement level (a
     single path evaluation per level); the grids are the reference's, value for value."""
     pts = np.array([path.path_interval[0], path.path_interval[1]], dtype=float)
-    converged = False
-    for _ in range(max_iteration):
+    last_pass = 0
+    for last_pass in range(max_iteration):
         lo, hi = pts[:-1], pts[1:]
         mid, seg = 0.5 * (lo + hi), hi - lo
         curv = np.abs(0.5 * np.reshape(path(mid, 2), (len(mid), -1)) * (seg ** 2)[:, None]).max(axis=1)
         split = (seg > max_seg_length) | (curv > max_err_threshold)
         if not split.any():
-            converged = True
             break
         pts = np.sort(np.concatenate([pts, mid[split]]))
     while len(pts) < min_nb_points:
         pts = np.sort(np.concatenate([pts, 0.5 * (pts[:-1] + pts[1:])]))
-    if not converged:
+    # the reference's verdict (:119-120): failure is "the refinement used its last allowed pass" -- also when that
+    # very pass found nothing left to split
+    if last_pass == max_iteration - 1:
         raise ValueError("Unable to find a good gridpoint for this path.")
     return [float(v) for v in pts]

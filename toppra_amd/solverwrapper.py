@@ -116,12 +116,18 @@ class hipSeidelWrapper(SolverWrapper):
     def _args(self):
         return self._coef, self._breaks, self.path_discretization, self._vlim, self._alim
 
+    # (every pass reads and updates self._active, the reference object's warm-start state: a sequence of passes on
+    # one instance -- examples/plot_kinematics.py:48,72 -- pivots in the reference's order and returns its bits)
+    # Boundary velocities are squared HERE, with the reference's own expression on the caller's own objects
+    # (`sd ** 2`: libm pow for Python floats, which is one ulp off sd * sd now and then; numpy's square for numpy
+    # scalars), and handed down as x = sd^2 (TPR_BOUNDARY_SQUARED).
     def controllable_sets(self, sdmin, sdmax):
-        return batch.controllable_sets_batch(*self._args(), np.array([sdmin], dtype=np.float64),
-                                             np.array([sdmax], dtype=np.float64), self._interp)[0]
+        return batch.controllable_sets_batch(*self._args(), np.array([sdmin ** 2], dtype=np.float64),
+                                             np.array([sdmax ** 2], dtype=np.float64), self._interp, active=self._active,
+                                             squared=True)[0]
 
     def feasible_sets(self):
-        return batch.feasible_sets_batch(*self._args(), self._interp)[0]
+        return batch.feasible_sets_batch(*self._args(), self._interp, active=self._active)[0]
 
     def reachable_sets(self, sdmin, sdmax):
         L, X = batch.reachable_sets_batch(*self._args(), np.array([sdmin], dtype=np.float64),
@@ -136,7 +142,7 @@ class hipSeidelWrapper(SolverWrapper):
         st = self._call_state
         if st is None:
             sd0, sd1 = np.zeros(1), np.zeros(1)
-            p, keep = _capi.make_problem(*self._args(), sd0, sd1, self._interp)
+            p, keep = _capi.make_problem(*self._args(), sd0, sd1, self._interp, active=self._active, squared=True)
             N = self.N
             out = {"sd2": np.empty((1, N + 1)), "sd": np.empty((1, N + 1)), "u": np.empty((1, N)),
                    "K": np.empty((1, N + 1, 2)), "status": np.empty((1,), dtype=np.int32)}
@@ -146,8 +152,8 @@ class hipSeidelWrapper(SolverWrapper):
             st = self._call_state = (sd0, sd1, C.byref(p), C.byref(r), _capi.load().tpr_solve_batch, views,
                                      out["status"], (p, r, keep, out))
         sd0, sd1, pref, rref, fn, views, status = st[:7]
-        sd0[0] = sd_start
-        sd1[0] = sd_end
+        sd0[0] = sd_start ** 2
+        sd1[0] = sd_end ** 2
         _capi.init()
         rc = fn(pref, rref, None)
         if rc != 0:
