@@ -61,6 +61,18 @@ extern "C" {
  * tests/test_gpu_fullsize.py); this flag exists for A/B testing and for callers who want the
  * iteration itself replicated.                                                                     */
 #define TPR_STRICT_SEIDEL 128
+/* Certificates of the throughput kernels (families 2, 3) in SOUND mode: a stage LP whose active pair MOVED against
+ * the previous stage is answered from a certificate only where the reference's own pivot sequence is predictable up
+ * to its last pivot (one violated row at a warm vertex that is still optimal for its own rows, the new partner
+ * inside that row's 1-D problem); every other moved pair runs the full iteration.  The default (fast) mode certifies
+ * moved pairs on conditions that bound the reference's LAST pivot only; an earlier pivot of the reference can still
+ * end ITS run with "infeasible" on an LP with a well separated optimum -- three constraint rows through one point to
+ * 1e-10, a sliver of 1e-14 (tests/test_gpu_fullsize.py::test_concurrent_rows_and_sliver_pivots_are_bit_exact:
+ * 1 in 1.5e5 trajectories of an adversarial family, ~1e-5 expected events per 65536 x 200 natural batch, none
+ * observed in 4e9 stage LPs) -- and the fast mode then returns the LP's optimum where the reference reports failure.
+ * Kernel family 4 (the latency kernel, which serves the drop-in class) is always sound.  Cost at the headline shape:
+ * see DESIGN.md section 3.1.                                                                                        */
+#define TPR_SOUND_CERTIFICATES 512
 
 /* per-trajectory status == ParameterizationReturnCode (algorithm/algorithm.py:49-62) */
 #define TPR_STATUS_OK 0

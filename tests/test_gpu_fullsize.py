@@ -245,7 +245,70 @@ def test_near_parallel_rows_are_bit_exact(gpu, B, d, N, seed):
     args = (coef, breaks, np.linspace(0, 1, N + 1), vlim, alim, None, sd1)
     full = batch.solve_batch(*args, strict=True)
     assert (full["status"] == 1).sum() >= 1  # the reference itself trips over some of them
+    for variant, sound in ((2, False), (3, False), (4, False), (2, True), (3, True)):
+        fast = batch.solve_batch(*args, variant=variant, sound=sound)
+        for k in ("K", "sd2", "u", "status"):
+            assert np.array_equal(fast[k], full[k], equal_nan=True), (variant, sound, k)
+
+
+@pytest.mark.parametrize("B,d,N,seed", [(16384, 7, 60, 1), (16384, 4, 50, 2), (16384, 3, 40, 3), (8192, 8, 48, 4)])
+def test_concurrent_rows_and_sliver_pivots_are_bit_exact(gpu, B, d, N, seed):
+    """Aimed at what the certificates' margins (A)-(C) do not bound by themselves: an
+    INTERMEDIATE pivot of the reference's iteration whose 1-D problem is a sliver -- rows visited earlier crossing
+    the pivot row's line at almost the same point -- which the reference's arithmetic may declare empty although
+    the LP has a well separated optimum elsewhere.  Generator: solve once, take a point P = (u_j, x_j) of the
+    solution at a random stage j (it lies on the boundary of that stage's feasible polygon, where the scans'
+    running optima pass), and move the acceleration limits of three joints so that their rows at s_j pass through P
+    -- through P + an offset of 0 or 1e-8 .. 1e-2 -- to within 1e-13 .. 1e-8, each from a random side: three rows
+    (with the original binding row: four) through one point at every scale between the solver's tolerances and the
+    certificates' margins, in every visiting order; whole-path scalings 1e-3 .. 1e1 on top.
+
+    What must hold (include/toppra_hip.h, TPR_SOUND_CERTIFICATES):
+      * family 4 (always sound) and families 2, 3 with sound=True return the full iteration's bits, failures included;
+      * families 2, 3 in their default (fast) mode may differ ONLY in trajectories the reference itself gives up on
+        (a sliver pivot ends its run "infeasible"; the fast certificate returns the LP's optimum), and in at most
+        1 in 2000 trajectories of this adversarial family (observed: 1 in 57344, seed 4)."""
+    rng = np.random.default_rng(4200 + seed)
+    data = batch.make_synthetic_batch(B, d, N, seed=4300 + seed)
+    scale = 10.0 ** rng.uniform(-3, 1, size=(B, 1, 1, 1))
+    scale[rng.random(B) < 0.5] = 1.0
+    coef = data["coef"] * scale
+    grid = data["grid"]
+    base = batch.solve_batch(coef, data["breaks"], grid, data["vlim"], data["alim"])
+    ok = base["status"] == 0
+    j = rng.integers(1, N - 1, size=B)
+    rows = np.arange(B)
+    u0 = np.where(ok, base["u"][rows, j], 0.0)
+    x0 = np.where(ok, base["sd2"][rows, j], 0.5)
+    off = np.where(rng.random(B) < 0.4, 0.0, 10.0 ** rng.uniform(-8, -2, size=B))
+    u0 = u0 + off * rng.standard_normal(B) * np.maximum(1.0, np.abs(u0))
+    x0 = np.maximum(x0 + off * rng.standard_normal(B) * np.maximum(1.0, np.abs(x0)), 0.0)
+    par = batch.constraint_params_batch(coef, data["breaks"], grid, data["vlim"], data["alim"])
+    qs, qss = par["qs"][rows, j], par["qss"][rows, j]            # [B, d]: q'(s_j), q''(s_j)
+    alim = data["alim"].copy()
+    joints = np.argsort(rng.random((B, d)), axis=1)[:, :3]      # three distinct joints per trajectory
+    for t in range(3):
+        k = joints[:, t]
+        val = qs[rows, k] * u0 + qss[rows, k] * x0                # the row's left-hand side at P
+        eps = 10.0 ** rng.uniform(-13, -8, size=B) * rng.choice([-1.0, 1.0], size=B) * np.maximum(1.0, np.abs(val))
+        upper = rng.random(B) < 0.5                               # which twin goes through P
+        width = 10 + 2 * rng.random(B)
+        amax = np.where(upper, val + eps, val + eps + width)
+        amin = np.where(upper, val + eps - width, val + eps)
+        alim[rows, k, 0], alim[rows, k, 1] = amin, amax
+    sd1 = np.where(rng.random(B) < 0.3, 0.2 * rng.random(B), 0.0)
+    args = (coef, data["breaks"], grid, data["vlim"], alim, None, sd1)
+    full = batch.solve_batch(*args, strict=True)
+    assert 0.02 < (full["status"] == 0).mean() < 0.999  # the family is hard: many of them fail in the reference too
+    for variant, sound in ((4, False), (2, True), (3, True)):
+        got = batch.solve_batch(*args, variant=variant, sound=sound)
+        for k in ("K", "sd2", "u", "status"):
+            assert np.array_equal(got[k], full[k], equal_nan=True), (variant, k)
     for variant in (2, 3):
         fast = batch.solve_batch(*args, variant=variant)
-        for k in ("K", "sd2", "u", "status"):
-            assert np.array_equal(fast[k], full[k], equal_nan=True), (variant, k)
+        bad = fast["status"] != full["status"]
+        for k in ("K", "sd2", "u"):
+            same = (fast[k] == full[k]) | (np.isnan(fast[k]) & np.isnan(full[k]))
+            bad |= ~same.reshape(B, -1).all(axis=1)
+        assert bad.sum() <= B // 2000, (variant, int(bad.sum()))
+        assert (full["status"][bad] != 0).all(), (variant, np.flatnonzero(bad)[:4])

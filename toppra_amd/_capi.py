@@ -22,6 +22,7 @@ BREAKS_PER_TRAJ = 16
 GRID_PER_TRAJ = 32
 STRICT_SEIDEL = 128
 BOUNDARY_SQUARED = 256
+SOUND_CERTIFICATES = 512
 
 STATUS_OK, STATUS_FAIL_UNCONTROLLABLE, STATUS_ERR_UNKNOWN = 0, 1, 2
 
@@ -213,7 +214,7 @@ def per_traj_vector(name, arr, B, like):
 
 
 def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
-                 variant=0, keep=None, strict=False, active=None, squared=False):
+                 variant=0, keep=None, strict=False, active=None, squared=False, sound=False):
     """Build a tpr_problem from arrays (all numpy or all torch-CUDA).  `keep` collects the
     converted arrays so they outlive the call.  Shapes and dtypes are validated here -- the C-ABI
     takes raw pointers and sizes, so a short or mistyped array would be read out of bounds:
@@ -248,7 +249,8 @@ def make_problem(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, int
         raise ValueError("grid needs at least two gridpoints")
     if not dev and not np.all(np.diff(grid, axis=-1) > 0):  # device grids are the caller's responsibility
         raise ValueError("grid must be strictly increasing")
-    flags = (DEVICE_PTRS if dev else 0) | (STRICT_SEIDEL if strict else 0) | (BOUNDARY_SQUARED if squared else 0)
+    flags = (DEVICE_PTRS if dev else 0) | (STRICT_SEIDEL if strict else 0) | (BOUNDARY_SQUARED if squared else 0) | \
+        (SOUND_CERTIFICATES if sound else 0)
     if breaks.ndim == 2:
         flags |= BREAKS_PER_TRAJ
     if grid.ndim == 2:

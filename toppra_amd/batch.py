@@ -59,7 +59,7 @@ def _prepare(coef):
 
 
 def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, interpolation=True,
-                want_sd=False, variant=0, strict=False, want_K=True, want_u=True, active=None):
+                want_sd=False, variant=0, strict=False, want_K=True, want_u=True, active=None, sound=False):
     """compute_parameterization for B trajectories.
 
     Returns dict(sd2[B,N+1], u[B,N], K[B,N+1,2], status[B] (+ sd[B,N+1] if want_sd)); failed
@@ -71,11 +71,14 @@ def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, inte
     ``strict=True`` (TPR_STRICT_SEIDEL) runs every stage LP through the reference's full Seidel
     iteration instead of answering it from a certified optimal vertex (same bits, slower).
 
+    ``sound=True`` (TPR_SOUND_CERTIFICATES): the throughput kernels certify a MOVED active pair only where the
+    reference's own pivot sequence is predictable (include/toppra_hip.h); the small-batch kernel always does.
+
     ``active`` [B, 4] int32 (in/out): the warm-start state ``active_c_up[2], active_c_down[2]`` of the
     reference's wrapper object, for sequences of passes on one instance (``None`` = a fresh instance)."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
-                                 variant, strict=strict, active=active)
+                                 variant, strict=strict, active=active, sound=sound)
     B, N = p.B, p.N
     out = {"sd2": _empty(coef, (B, N + 1)), "status": _empty(coef, (B,), "i32")}
     if want_u:
@@ -131,12 +134,12 @@ def robust_solve_batch(coef, breaks, grid, vlim, alim, ellipsoid, sd_start=None,
 
 
 def solve_batch_timed(coef, breaks, grid, vlim, alim, out, reps, sd_start=None, sd_end=None,
-                      interpolation=True, variant=0, strict=False):
+                      interpolation=True, variant=0, strict=False, sound=False):
     """bench.py helper: `reps` launches between two hipEvents on torch's current stream.
     Returns average ms per launch.  `out` is a dict from a previous solve_batch (device)."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation,
-                                 variant, strict=strict)
+                                 variant, strict=strict, sound=sound)
     r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out["u"]),
                          K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
     ms = C.c_float(0)
