@@ -89,6 +89,41 @@ def test_spline_fit_beyond_64_points(gpu):
             assert np.array_equal(coef[b], want) or np.max(np.abs(coef[b] - want)) <= 1e-9 * np.max(np.abs(want)), (m, bc)
 
 
+@pytest.mark.parametrize("B,d,N", [(300, 7, 200), (70, 1, 64), (9, 64, 30), (21, 33, 50), (100, 12, 3), (50, 5, 1),
+                                   (12, 65, 20)])
+def test_param_spline_fused_kernel_matches_the_generic_path(gpu, B, d, N):
+    """The single-kernel ParametrizeSpline (a wave owns floor(64/d) trajectories, the tridiagonal matrix eliminated
+    once per trajectory alongside every dof's right-hand side) against the generic path (time stamps + waypoints
+    kernel, then the scipy/dgtsv-exact fit kernel) -- every output bit for bit.  The velocity profiles are made to
+    exercise what the streaming elimination has to get right: gridpoints dropped from the knot vector (huge
+    velocities: reached in < 1e-8 s), ragged knot counts down to 1 and 2, standing stretches (5 s steps next to
+    milliseconds: dgtsv exchanges rows there), NaN profiles, per-trajectory grids."""
+    rng = np.random.default_rng(1000 * d + N)
+    data = batch.make_synthetic_batch(B, d, N, seed=5 + d)
+    sd = 0.2 + 3 * rng.random((B, N + 1))
+    hole = rng.random((B, N + 1)) < 0.08
+    sd[hole] = 1e12                                   # dropped gridpoints (pairs of them: sd_avg huge)
+    sd[:, 1:][hole[:, :-1] & (rng.random((B, N)) < 0.7)] = 1e12
+    still = rng.random((B, N + 1)) < 0.05
+    sd[still] = 0.0
+    sd[:, 1:][still[:, :-1] & (rng.random((B, N)) < 0.5)] = 0.0  # two zeros in a row: the 5 s rule
+    sd[0] = 1e12                                      # everything dropped: a single knot
+    if B > 3:
+        sd[1, 1:] = 1e12
+        sd[1, -1] = 1.0                               # two knots
+        sd[2, N // 2:] = np.nan
+        sd[3, 0] = 0.0
+    grid = data["grid"][None] + 0 * rng.random((B, 1))
+    grid = np.sort(np.clip(grid + 0.3 / N * rng.random((B, N + 1)), 0, None), axis=1)
+    grid[:, 0], grid[:, -1] = data["grid"][0], data["grid"][-1]
+    for g in (data["grid"], grid):
+        new = batch.param_spline_batch(data["coef"], data["breaks"], g, sd)
+        old = batch.param_spline_batch(data["coef"], data["breaks"], g, sd, variant=1)
+        assert new["counts"][0] == 1 and len(np.unique(new["counts"])) >= min(B, 3) - 1
+        for k in ("counts", "knot_times", "coef"):
+            assert np.array_equal(new[k], old[k], equal_nan=True), k
+
+
 @pytest.mark.parametrize("kind", ["ParametrizeSpline", "ParametrizeConstAccel"])
 def test_failed_trajectories_have_nan_durations(gpu, kind):
     """A batch with trajectories that cannot be parameterized (uncontrollable start velocity): their status is

@@ -250,14 +250,15 @@ def const_accel_eval_batch(coef, breaks, grid, sd, ts, us, times, order=0):
     return out
 
 
-def param_spline_batch(coef, breaks, grid, sd):
+def param_spline_batch(coef, breaks, grid, sd, variant=0):
     """ParametrizeSpline (the reference's default output parametrizer, parametrizer.py:161-196) for B
     trajectories: sd [B, N+1] -> dict(knot_times [B, N+1], counts [B], coef [B, 4, N, d]): the cubic spline in
     time through q(s_i) at the gridpoint times, clamped to q'(s) sd at both ends.  Entries of
     ``knot_times`` from ``counts[b]`` on are padding (gridpoints reached in no time are dropped, as in the
-    reference).  Evaluate with :func:`ppoly_eval_batch`."""
+    reference).  Evaluate with :func:`ppoly_eval_batch`.  ``variant=1`` forces the generic two-kernel path (the one
+    that serves d > 64); the default is the single fused kernel -- same bits."""
     _prepare(coef)
-    p, keep = _capi.make_problem(coef, breaks, grid, None, None)
+    p, keep = _capi.make_problem(coef, breaks, grid, None, None, variant=variant)
     dev = _capi.is_torch_cuda(coef)
     if dev:
         _capi.check_tensor("sd", sd, coef)

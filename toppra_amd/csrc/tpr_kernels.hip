@@ -943,7 +943,33 @@ int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_
     K.tk = S.out(knot_times, B * (N + 1));
     K.counts = S.out(counts, B);
     double *dcoef = S.out(coef_t, B * 4 * N * d);
-    // internal: waypoints q(s_i) and the two end derivatives
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (B > 0 && d <= 64 && N <= 65535 && p->variant != 1) {
+        // one kernel (tpr_spline.hip.inc): a wave owns floor(64/d) trajectories; workspace = the eliminated right-hand
+        // sides [tasks][N+1][64], the eliminated matrix rows [tasks][N+1][3][tpw], the knots' path positions [B][N+1]
+        tpr::ParamFusedArgs F{};
+        F.K = K; F.coef_t = dcoef; F.tpw = std::min(64 / (int)d, tpr::kPsMaxTpw);
+        const size_t tasks = (B + F.tpw - 1) / F.tpw;
+        const size_t rhs_n = tasks * (N + 1) * 64, rows_n = tasks * (N + 1) * 3 * F.tpw, sk_n = B * (N + 1);
+        void *ws = nullptr;
+        HIP_TRY(hipMallocAsync(&ws, (rhs_n + rows_n + sk_n) * sizeof(double), stream));
+        S.owned.push_back(ws);
+        F.rhs = static_cast<double *>(ws);
+        F.rows = F.rhs + rhs_n;
+        F.sk = F.rows + rows_n;
+        int tile = tpr::kPsTile;
+#if TPR_PS_EXPERIMENT
+        if (const char *e = getenv("TPR_PS_TILE")) tile = atoi(e);
+        if (const char *e = getenv("TPR_PS_DEBUG")) F.debug = atoi(e);
+#endif
+        const size_t lds = ((size_t)(tile + 1) * (128 + 5 * F.tpw) + 64) * sizeof(double) + (size_t)F.tpw * sizeof(int);
+        if (tile == 4) hipLaunchKernelGGL(tpr::param_spline_fused_kernel<4>, dim3((unsigned)tasks), dim3(64), lds, stream, F);
+        else if (tile == 16) hipLaunchKernelGGL(tpr::param_spline_fused_kernel<16>, dim3((unsigned)tasks), dim3(64), lds, stream, F);
+        else hipLaunchKernelGGL(tpr::param_spline_fused_kernel<tpr::kPsTile>, dim3((unsigned)tasks), dim3(64), lds, stream, F);
+        HIP_TRY(S.finish());
+        return TPR_E_OK;
+    }
+    // generic path (d > 64, or variant 1): waypoints q(s_i) and the two end derivatives, then the spline-fit kernel
     void *ws = nullptr;
     if (S.err == hipSuccess && B > 0) S.err = hipMallocAsync(&ws, (B * (N + 1) * d + 2 * B * d) * sizeof(double), stream);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
