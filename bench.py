@@ -286,7 +286,7 @@ def baseline_configs(torch, tb, dev):
     res["C4_robust_batch16384_d7_N100"] = {
         "batch": 16384, "dof": 7, "gridpoints": 100, "ms": ms4, "trajectories_per_s": 16384 / ms4 * 1e3,
         "note": "RobustLinearConstraint over JointAcceleration, ellipsoid (1e-3, 5e-2, 9e-3); the reference's ECOS stage "
-                "problems solved exactly; parity pinned to an independent SOCP solver at 1e-7 (tests/test_gpu_robust.py)"}
+                "problems solved exactly; parity unpinned against ECOS (absent), cross-checked at 1e-7 against an independent exact solver (tests/test_gpu_robust.py)"}
     res["C5_batch524288_8gpu"] = "this bench with --gpus 8 (65536 trajectories per rank + RCCL gather of sd^2)"
     # PCIe-inclusive: numpy in -> numpy out through the host-buffer entry (H2D 59 MB, kernel, D2H)
     datah = tb.make_synthetic_batch(65536, 7, 200)

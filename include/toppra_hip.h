@@ -148,7 +148,9 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream);
 int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired, double atol,
                                      const tpr_result *r, double *alpha, void *stream);
 
-/* Robust TOPP-RA (BASELINE config 4) -- PARITY UNPINNED, see csrc/tpr_robust.hip.inc.  Replaces
+/* Robust TOPP-RA (BASELINE config 4) -- PARITY UNPINNED against ECOS (absent here; the
+ * reference holds no golden vectors for it); cross-checked at 1e-7 against an independent exact solver
+ * (oracle/robust_independent.py, tests/test_gpu_robust.py); see csrc/tpr_robust.hip.inc.  Replaces
  * TOPPRA([JointVelocityConstraint, RobustLinearConstraint(JointAccelerationConstraint, ellipsoid)],
  * ..., solver_wrapper="ecos"): compute_parameterization (+ compute_feasible_sets into X when X !=
  * NULL) with the stage problems ecosWrapper.solve_stagewise_optim builds

