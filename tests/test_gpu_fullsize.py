@@ -186,6 +186,28 @@ def test_feasible_sets_on_fast_kernel(gpu, oracle, B, d, N):
         assert np.array_equal(X[b], w.compute_feasible_sets(), equal_nan=True), b
 
 
+@pytest.mark.parametrize("interp", [True, False])
+def test_feasible_sets_on_the_certified_lane_kernel(gpu, oracle, interp):
+    """compute_feasible_sets at the headline shape runs family 3 (cert_feasible_kernel: certified answers for the min-x /
+    max-x LPs of every stage, the reference's warm-start state carried along, the last gridpoint's own row set): every
+    stage of all 65 536 trajectories -- plain and scaled by 1e-6..1 -- against the reference's full iteration for every
+    LP (rows-across-lanes kernel, strict), fast and sound certificates, and a sample against the oracle."""
+    B, d, N = 65536, 7, 200
+    data = batch.make_synthetic_batch(B, d, N, seed=77)
+    rng = np.random.default_rng(77)
+    scale = np.where(rng.random((B, 1, 1, 1)) < 0.5, 1.0, 10.0 ** rng.uniform(-6, 0, size=(B, 1, 1, 1)))
+    coef = data["coef"] * scale
+    args = (coef, data["breaks"], data["grid"], data["vlim"], data["alim"], interp)
+    full = batch.feasible_sets_batch(*args, variant=2, strict=True)
+    for kw in (dict(), dict(variant=3), dict(variant=3, sound=True)):   # (auto picks family 3 at this size)
+        X = batch.feasible_sets_batch(*args, **kw)
+        assert np.array_equal(X, full, equal_nan=True), kw
+    for b in range(0, B, 4099):
+        flags = oracle.FLAG_VEL | oracle.FLAG_ACC | (oracle.FLAG_INTERP if interp else 0)
+        w = oracle.Wrapper(coef[b], data["breaks"], data["grid"], data["vlim"][b], data["alim"][b], flags=flags)
+        assert np.array_equal(full[b], w.compute_feasible_sets(), equal_nan=True), b
+
+
 def test_headline_batch_oracle_parity_every_trajectory(gpu, oracle):
     """All 65 536 trajectories of the headline batch, and an irregular batch of the same size (asymmetric
     and positive lower velocity limits, standing joints, non-uniform knots and grid, boundary velocities),

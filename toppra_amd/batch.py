@@ -176,10 +176,16 @@ def reachable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpola
     return (L, X) if want_X else L
 
 
-def feasible_sets_batch(coef, breaks, grid, vlim, alim, interpolation=True, active=None):
-    """compute_feasible_sets for B trajectories -> X[B,N+1,2] (``active``: see solve_batch)."""
+def feasible_sets_batch(coef, breaks, grid, vlim, alim, interpolation=True, active=None, variant=0, strict=False,
+                        sound=False):
+    """compute_feasible_sets for B trajectories -> X[B,N+1,2] (``active``: see solve_batch).
+
+    ``variant``: 0 = auto (one trajectory per wave for a handful of trajectories or with ``active``; the certified lane
+    kernel from 8192 trajectories up to 8 dof; rows across lanes otherwise), 2 / 3 / 4 force a kernel family.
+    ``strict`` (TPR_STRICT_SEIDEL): the reference's full iteration for every LP; ``sound``: see solve_batch."""
     _prepare(coef)
-    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation, active=active)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation, active=active, variant=variant,
+                                 strict=strict, sound=sound)
     X = _empty(coef, (p.B, p.N + 1, 2))
     _capi.check(_capi.load().tpr_feasible_sets_batch(C.byref(p), _capi.ptr(X), _stream_ptr(coef)))
     return X

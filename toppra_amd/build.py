@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtoppra_hip.so")
-SOURCES = ["tpr_kernels.hip"]
+SOURCES = ["tpr_kernels.hip", "tpr_cert_tu.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
@@ -40,18 +40,55 @@ def stale():
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in deps())
 
 
+CERT_DOFS = (1, 2, 3, 4, 5, 6, 7, 8)   # kernel family 3: one translation unit per dof (csrc/tpr_cert_tu.hip)
+
+
+def _compile_and_link(target, flags, defines, verbose, single_tu):
+    """hipcc the translation units in parallel (the certified lane kernels are most of the compile time: one unit per
+    dof), then link the objects into `target`.  Instrumented development builds (`defines`) are ONE translation unit:
+    their counters are device globals, and they instantiate 7 dof only."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    cc = hipcc()
+    cflags = [f for f in flags if f != "-shared"]
+    dflags = ["-D" + d for d in defines]
+    main = os.path.join(CSRC, "tpr_kernels.hip")
+    if single_tu:
+        cmd = [cc] + flags + dflags + ["-DTPR_SINGLE_TU", "-DTPR_CERT_DEV", "-o", target, main]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        return target
+    with tempfile.TemporaryDirectory(prefix="tpr_build_") as tmp:
+        jobs = [(main, os.path.join(tmp, "main.o"), [])]
+        for d in CERT_DOFS:
+            jobs.append((os.path.join(CSRC, "tpr_cert_tu.hip"), os.path.join(tmp, "cert%d.o" % d), ["-DTPR_TU_D=%d" % d]))
+
+        def run(job):
+            src, obj, extra = job
+            cmd = [cc] + cflags + dflags + extra + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=CSRC)
+            return obj
+
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(run, jobs))
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+    return target
+
+
 def build_tolerance(out=None, verbose=False):
     """The opt-in measurement build "what does bit-exactness cost" (DESIGN.md): same sources with
     -DTPR_TOLERANCE_MODE (certified vertices returned as they are, no replication of the reference's
     last-pivot arithmetic), contracted multiply-adds and reciprocal-based division.  Results agree with the
     product to ~1e-12, status codes identical; it is NOT the product library and nothing loads it by default."""
     target = os.path.abspath(out) if out else os.path.join(HERE, "libtoppra_hip_tol.so")
-    flags = [f for f in FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast", "-freciprocal-math", "-DTPR_TOLERANCE_MODE"]
-    cmd = [hipcc()] + flags + ["-o", target] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
-    return target
+    flags = [f for f in FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast", "-freciprocal-math"]
+    return _compile_and_link(target, flags, ["TPR_TOLERANCE_MODE"], verbose, single_tu=False)
 
 
 def build(force=False, verbose=False, defines=(), out=None):
@@ -62,11 +99,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     if not defines and not out and not force and not stale():
         return LIB
     os.makedirs(os.path.dirname(target), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-D" + d for d in defines] + ["-o", target] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
-    return target
+    return _compile_and_link(target, FLAGS, list(defines), verbose, single_tu=bool(defines))
 
 
 def ensure_built(verbose=False):

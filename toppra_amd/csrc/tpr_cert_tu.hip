@@ -1,0 +1,72 @@
+// tpr_cert_tu.hip -- translation unit of kernel family 3 (tpr_cert.hip.inc) for ONE dof.
+//
+// The certified lane kernels are instantiated per dof and per (sd output, grid in LDS, discretisation, certificate mode):
+// 8 x 16 heavy kernels, most of the library's compile time.  build.py compiles this file once per dof
+// (-DTPR_TU_D=<dof>), in parallel with tpr_kernels.hip, and links the objects into libtoppra_hip.so; the entry points
+// below are the only interface (declared in tpr_kernels.hip).  Development builds with instrumentation defines
+// (-DTPR_DEBUG_PREDICT ..., whose counters are device globals of ONE translation unit) include this file from
+// tpr_kernels.hip instead (TPR_SINGLE_TU).
+#include <hip/hip_runtime.h>
+
+#include "../../include/toppra_hip.h"
+#include "tpr_device.hpp"
+#include "tpr_group.hip.inc"
+#include "tpr_cert.hip.inc"
+
+#ifndef TPR_TU_D
+#error "compile with -DTPR_TU_D=<dof 1..8>"
+#endif
+
+#define TPR_TU_CAT2(a, b) a##b
+#define TPR_TU_CAT(a, b) TPR_TU_CAT2(a, b)
+
+// Launch the certified lane kernel for TPR_TU_D dof: the fused solve, or the backward scan alone (G.backward_only).
+// Returns 0, or -1 when the launch geometry cannot be met (never for supported shapes).
+extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, hipStream_t stream) {
+    constexpr int D = TPR_TU_D, BS = 64;
+    const tpr::GroupArgs &G = *Gp;
+    const dim3 grid((G.B + BS - 1) / BS), block(BS);
+    // the shared grid goes to LDS only while four blocks still fit a CU (160 KB): a fifth of the
+    // 1024 blocks of a 65536-trajectory batch would otherwise wait for a second round
+    const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
+    const size_t static_lds = (((6 * D + 6) > 24 ? (6 * D + 6) : 24) * BS + tpr::kCertXch * BS +
+                               tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
+    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && static_lds + grid_bytes <= 40 * 1024;
+    const size_t lds = grid_lds ? grid_bytes : 0;
+    const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
+    // One 64-lane block per wave; ~39 KB of LDS per block leaves one wave per SIMD, which the kernel
+    // is written for (the whole register file, stalls covered by unrolled independent row work).
+#define TPR_LAUNCH_CERT(SD, GL, IN, SO) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, SD, GL, IN, SO>), grid, block, lds, stream, G)
+#define TPR_LAUNCH_CERT3(SD, GL, IN) do { if (sound) TPR_LAUNCH_CERT(SD, GL, IN, true); else TPR_LAUNCH_CERT(SD, GL, IN, false); } while (0)
+    if (G.flags & TPR_ACC_INTERPOLATION) {
+        if (G.sd) { if (grid_lds) TPR_LAUNCH_CERT3(true, true, true); else TPR_LAUNCH_CERT3(true, false, true); }
+        else { if (grid_lds) TPR_LAUNCH_CERT3(false, true, true); else TPR_LAUNCH_CERT3(false, false, true); }
+    } else {  // Collocation
+        if (G.sd) { if (grid_lds) TPR_LAUNCH_CERT3(true, true, false); else TPR_LAUNCH_CERT3(true, false, false); }
+        else { if (grid_lds) TPR_LAUNCH_CERT3(false, true, false); else TPR_LAUNCH_CERT3(false, false, false); }
+    }
+#undef TPR_LAUNCH_CERT3
+#undef TPR_LAUNCH_CERT
+    return 0;
+}
+
+// compute_feasible_sets on the certified lane design (cert_feasible_kernel): X [B][N+1][2].
+extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feasible_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, double *X, hipStream_t stream) {
+    constexpr int D = TPR_TU_D, BS = 64;
+    const tpr::GroupArgs &G = *Gp;
+    const dim3 grid((G.B + BS - 1) / BS), block(BS);
+    const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
+    const size_t static_lds = (((6 * D + 6) > 24 ? (6 * D + 6) : 24) * BS + tpr::kCertXch * BS +
+                               tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
+    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && static_lds + grid_bytes <= 40 * 1024;
+    const size_t lds = grid_lds ? grid_bytes : 0;
+    const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
+    const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;
+#define TPR_LAUNCH_FEAS(GL, IN, SO) hipLaunchKernelGGL((tpr::cert_feasible_kernel<D, BS, GL, IN, SO>), grid, block, lds, stream, G, X)
+#define TPR_LAUNCH_FEAS2(GL, IN) do { if (sound) TPR_LAUNCH_FEAS(GL, IN, true); else TPR_LAUNCH_FEAS(GL, IN, false); } while (0)
+    if (interp) { if (grid_lds) TPR_LAUNCH_FEAS2(true, true); else TPR_LAUNCH_FEAS2(false, true); }
+    else { if (grid_lds) TPR_LAUNCH_FEAS2(true, false); else TPR_LAUNCH_FEAS2(false, false); }
+#undef TPR_LAUNCH_FEAS2
+#undef TPR_LAUNCH_FEAS
+    return 0;
+}

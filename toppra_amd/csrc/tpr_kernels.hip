@@ -15,11 +15,36 @@
 #include "tpr_device.hpp"
 #include "tpr_lane.hip.inc"
 #include "tpr_group.hip.inc"
-#include "tpr_cert.hip.inc"
 #include "tpr_wave.hip.inc"
 #include "tpr_spline.hip.inc"
 #include "tpr_param.hip.inc"
 #include "tpr_robust.hip.inc"
+
+// kernel family 3, one translation unit per dof (tpr_cert_tu.hip)
+#ifdef TPR_SINGLE_TU  // development builds with instrumentation: everything in this translation unit, 7 dof only
+#define TPR_TU_D 7
+#include "tpr_cert_tu.hip"
+#undef TPR_TU_D
+#else
+extern "C" {
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_1(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_1(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_2(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_2(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_3(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_3(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_4(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_4(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_5(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_5(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_6(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_6(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_7(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_7(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_8(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_8(const tpr::GroupArgs *, double *, hipStream_t);
+}
+#endif
 
 namespace {
 
@@ -238,30 +263,46 @@ bool cert_supported(const tpr::BatchArgs &A) {
            (A.backward_only || (A.sd2 && A.u && A.status));
 }
 
-template <int D>
+// Kernel family 3 lives in its own translation units, one per dof (tpr_cert_tu.hip; build.py compiles them in parallel).
 int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
-    constexpr int BS = 64;
     tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
                      A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status, A.sd_end_hi, A.backward_only};
-    const dim3 grid((A.B + BS - 1) / BS), block(BS);
-    // the shared grid goes to LDS only while four blocks still fit a CU (160 KB): a fifth of the
-    // 1024 blocks of a 65536-trajectory batch would otherwise wait for a second round
-    const size_t grid_bytes = (size_t)(A.N + 1) * sizeof(double);
-    const size_t static_lds = (((6 * D + 6) > 24 ? (6 * D + 6) : 24) * BS + tpr::kCertXch * BS + tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
-    const bool grid_lds = !(A.flags & TPR_GRID_PER_TRAJ) && static_lds + grid_bytes <= 40 * 1024;
-    const size_t lds = grid_lds ? grid_bytes : 0;
-    // One 64-lane block per wave; ~33 KB of LDS per block leaves one wave per SIMD, which the kernel
-    // is written for (the whole register file, stalls covered by unrolled independent row work).
-#define TPR_LAUNCH_CERT(SD, GL, IN) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, SD, GL, IN>), grid, block, lds, stream, G)
-    if (A.flags & TPR_ACC_INTERPOLATION) {
-        if (A.sd) { if (grid_lds) TPR_LAUNCH_CERT(true, true, true); else TPR_LAUNCH_CERT(true, false, true); }
-        else { if (grid_lds) TPR_LAUNCH_CERT(false, true, true); else TPR_LAUNCH_CERT(false, false, true); }
-    } else {  // Collocation
-        if (A.sd) { if (grid_lds) TPR_LAUNCH_CERT(true, true, false); else TPR_LAUNCH_CERT(true, false, false); }
-        else { if (grid_lds) TPR_LAUNCH_CERT(false, true, false); else TPR_LAUNCH_CERT(false, false, false); }
+    switch (A.d) {
+#ifndef TPR_CERT_DEV  // development builds instantiate 7 dof only
+        case 1: return tpr_tu_cert_launch_1(&G, stream);
+        case 2: return tpr_tu_cert_launch_2(&G, stream);
+        case 3: return tpr_tu_cert_launch_3(&G, stream);
+        case 4: return tpr_tu_cert_launch_4(&G, stream);
+        case 5: return tpr_tu_cert_launch_5(&G, stream);
+        case 6: return tpr_tu_cert_launch_6(&G, stream);
+        case 8: return tpr_tu_cert_launch_8(&G, stream);
+#endif
+        case 7: return tpr_tu_cert_launch_7(&G, stream);
     }
-#undef TPR_LAUNCH_CERT
-    return TPR_E_OK;
+    return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
+}
+
+// compute_feasible_sets on the certified lane design: the constraint sets and dofs of family 3, fresh warm-start state
+bool cert_feasible_supported(const tpr::BatchArgs &A) {
+    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= 8 && !(A.flags & TPR_STRICT_SEIDEL) && !A.active;
+}
+
+int launch_cert_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream) {
+    tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
+                     A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
+    switch (A.d) {
+#ifndef TPR_CERT_DEV
+        case 1: return tpr_tu_cert_feasible_launch_1(&G, X, stream);
+        case 2: return tpr_tu_cert_feasible_launch_2(&G, X, stream);
+        case 3: return tpr_tu_cert_feasible_launch_3(&G, X, stream);
+        case 4: return tpr_tu_cert_feasible_launch_4(&G, X, stream);
+        case 5: return tpr_tu_cert_feasible_launch_5(&G, X, stream);
+        case 6: return tpr_tu_cert_feasible_launch_6(&G, X, stream);
+        case 8: return tpr_tu_cert_feasible_launch_8(&G, X, stream);
+#endif
+        case 7: return tpr_tu_cert_feasible_launch_7(&G, X, stream);
+    }
+    return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
 }
 
 template <int D, int L>
@@ -388,19 +429,7 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
         case 3: {
             if (!cert_supported(A))
                 return fail(TPR_E_UNSUPPORTED, "variant 3 needs acceleration+interpolation, d <= 8, sd2/u/status outputs, default mode");
-            switch (A.d) {
-#ifndef TPR_CERT_DEV  // development builds instantiate 7 dof only
-                case 1: return launch_cert<1>(A, stream);
-                case 2: return launch_cert<2>(A, stream);
-                case 3: return launch_cert<3>(A, stream);
-                case 4: return launch_cert<4>(A, stream);
-                case 5: return launch_cert<5>(A, stream);
-                case 6: return launch_cert<6>(A, stream);
-                case 8: return launch_cert<8>(A, stream);
-#endif
-                case 7: return launch_cert<7>(A, stream);
-            }
-            return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
+            return launch_cert(A, stream);
         }
         case 2: {
             if (!group_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 2: dof out of range");
@@ -772,12 +801,21 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
     A.active = S.out(p->active, (size_t)p->B * 4, true);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (A.B > 0) {
-        if (wave_supported(A) && (A.active || A.B <= 64 || !group_supported(A))) {
+        // p->variant: 0 = auto, 2 / 3 / 4 force a kernel family (1: the generic lane kernel)
+        const int want = p->variant;
+        const bool wave_auto = wave_supported(A) && (A.active || A.B <= 64 || !group_supported(A));
+        if (want == 3 && !cert_feasible_supported(A))
+            return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 8, default mode, no warm-start state");
+        if (want == 4 && !wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables");
+        if (want == 4 || (want == 0 && wave_auto)) {
             // one trajectory per wave: a handful of trajectories (latency), 17..32 dof, or the wrapper object's
             // warm-start state in / out
             A.feasible_X = dX;
             if (int rc = launch_wave(A, stream)) return rc;
-        } else if (group_supported(A)) {
+        } else if (want == 3 || (want == 0 && cert_feasible_supported(A) && A.B >= 8192)) {
+            // one trajectory per lane, certified answers (family 3): a fixed-latency round up to 65536 trajectories
+            if (int rc = launch_cert_feasible(A, dX, stream)) return rc;
+        } else if (group_supported(A) && want != 1) {
             if (int rc = dispatch_group_feasible(A, dX, stream)) return rc;
         } else {
             hipLaunchKernelGGL(tpr::lane_feasible_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dX);
