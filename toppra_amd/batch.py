@@ -94,13 +94,15 @@ def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, inte
 
 
 def solve_desired_duration_batch(coef, breaks, grid, vlim, alim, desired_duration, sd_start=None, sd_end=None,
-                                 atol=1e-5):
+                                 atol=1e-5, variant=0, interpolation=True):
     """TOPPRAsd.compute_parameterization for B trajectories (desired_duration_algorithm.py:42-191).
 
     ``desired_duration``: scalar or [B] seconds.  Returns dict(sd2, sd, u, K, status, alpha): alpha is
-    the blend between the fastest (1) and slowest (0) parameterizations found by bisection."""
+    the blend between the fastest (1) and slowest (0) parameterizations found by bisection.
+    ``variant``: 0 = auto (from 14336 trajectories up to 8 dof: the certified lane kernel runs the backward scan and both
+    forward profiles in one launch; rows across lanes otherwise), 2 / 3 force one."""
     _prepare(coef)
-    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, True)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation, variant=variant)
     B, N = p.B, p.N
     desired = _capi.per_traj_vector("desired_duration", desired_duration, B, coef)
     out = {"sd2": _empty(coef, (B, N + 1)), "sd": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)),

@@ -70,3 +70,24 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feas
 #undef TPR_LAUNCH_FEAS
     return 0;
 }
+
+// TOPPRAsd: backward scan + the fastest / slowest forward profiles in one launch (cert_solve_kernel<..., SDFWD = true>).
+extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, hipStream_t stream) {
+    constexpr int D = TPR_TU_D, BS = 64;
+    const tpr::GroupArgs &G = *Gp;
+    const dim3 grid((G.B + BS - 1) / BS), block(BS);
+    const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
+    const size_t cols = ((6 * D + 6) > 32 ? (6 * D + 6) : 32) * BS;
+    const size_t static_lds = (cols + tpr::kCertXch * BS + tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
+    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && static_lds + grid_bytes <= 40 * 1024;
+    const size_t lds = grid_lds ? grid_bytes : 0;
+    const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
+    const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;
+#define TPR_LAUNCH_SD(GL, IN, SO) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, false, GL, IN, SO, true>), grid, block, lds, stream, G)
+#define TPR_LAUNCH_SD2(GL, IN) do { if (sound) TPR_LAUNCH_SD(GL, IN, true); else TPR_LAUNCH_SD(GL, IN, false); } while (0)
+    if (interp) { if (grid_lds) TPR_LAUNCH_SD2(true, true); else TPR_LAUNCH_SD2(false, true); }
+    else { if (grid_lds) TPR_LAUNCH_SD2(true, false); else TPR_LAUNCH_SD2(false, false); }
+#undef TPR_LAUNCH_SD2
+#undef TPR_LAUNCH_SD
+    return 0;
+}

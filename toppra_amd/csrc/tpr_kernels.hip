@@ -29,20 +29,28 @@
 extern "C" {
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_1(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_1(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_1(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_2(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_2(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_2(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_3(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_3(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_3(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_4(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_4(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_4(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_5(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_5(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_5(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_6(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_6(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_6(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_7(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_7(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_7(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_8(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_8(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_8(const tpr::GroupArgs *, hipStream_t);
 }
 #endif
 
@@ -301,6 +309,25 @@ int launch_cert_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream)
         case 8: return tpr_tu_cert_feasible_launch_8(&G, X, stream);
 #endif
         case 7: return tpr_tu_cert_feasible_launch_7(&G, X, stream);
+    }
+    return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
+}
+
+// TOPPRAsd on family 3: backward scan and both forward profiles in one launch
+int launch_cert_sd(const tpr::BatchArgs &A, double *xf, double *uf, double *xl, double *ul, hipStream_t stream) {
+    tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
+                     A.sd_start, A.sd_end, A.sd2, nullptr, A.u, A.K, A.status, nullptr, 0, xf, uf, xl, ul};
+    switch (A.d) {
+#ifndef TPR_CERT_DEV
+        case 1: return tpr_tu_cert_sd_launch_1(&G, stream);
+        case 2: return tpr_tu_cert_sd_launch_2(&G, stream);
+        case 3: return tpr_tu_cert_sd_launch_3(&G, stream);
+        case 4: return tpr_tu_cert_sd_launch_4(&G, stream);
+        case 5: return tpr_tu_cert_sd_launch_5(&G, stream);
+        case 6: return tpr_tu_cert_sd_launch_6(&G, stream);
+        case 8: return tpr_tu_cert_sd_launch_8(&G, stream);
+#endif
+        case 7: return tpr_tu_cert_sd_launch_7(&G, stream);
     }
     return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
 }
@@ -645,30 +672,51 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
     A.K = S.out(r->K, B * (N + 1) * 2);
     A.status = S.out(r->status, B);
     double *dalpha = S.out(alpha, B);
-    // workspace: fastest / slowest profiles and a status array when the caller wants none
+    // workspace: fastest / slowest profiles, the bisection's worklist, a status / alpha array when the caller wants none
     double *ws = nullptr;
-    int32_t *wstatus = nullptr;
+    int32_t *wstatus = nullptr, *wlist = nullptr;
     const size_t per = 2 * (N + 1) + 2 * N;
-    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * per * sizeof(double) + 8, stream);
+    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * (per + (dalpha ? 0 : 1)) * sizeof(double) + 8, stream);
+    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&wlist), (B + 2) * sizeof(int32_t), stream);
     if (S.err == hipSuccess && !A.status) {
         S.err = hipMallocAsync(reinterpret_cast<void **>(&wstatus), B * sizeof(int32_t) + 4, stream);
         A.status = wstatus;
     }
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     S.owned.push_back(ws);
+    S.owned.push_back(wlist);
     if (wstatus) S.owned.push_back(wstatus);
+    if (!dalpha) dalpha = ws + B * per;
     if (A.B > 0) {
-        {  // backward scan -> K and the controllability verdict (the time-optimal forward scan is not needed)
-            tpr::BatchArgs Ab = A;
-            Ab.backward_only = 1;
+        double *xf = ws, *uf = ws + B * (N + 1), *xl = ws + B * (2 * N + 1), *ul = ws + B * (3 * N + 2);
+        tpr::BatchArgs Ab = A;
+        Ab.backward_only = 1;
+        // p->variant: 0 = auto; 2 / 3 force the rows-across-lanes scans / the certified lane kernel for both scans
+        const bool fused = p->variant == 3 || (p->variant == 0 && cert_supported(Ab) && A.B >= 14336);
+        if (fused) {
+            // family 3: backward scan + fastest / slowest forward profiles in ONE launch (cert_solve_kernel<SDFWD>)
+            if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 8, default mode");
+            if (int rc = launch_cert_sd(A, xf, uf, xl, ul, stream)) return rc;
+        } else {
+            // backward scan -> K and the controllability verdict (the time-optimal forward scan is not needed), then
+            // the two forward scans on the rows-across-lanes kernel
             if (int rc = launch_solve(p, Ab, stream)) return rc;
+            tpr::SdArgs F{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim, A.sd_start, A.K,
+                          A.status, xf, uf, xl, ul};
+            if (int rc = dispatch_sd_forward(A.d, F, stream)) return rc;
         }
-        tpr::SdArgs F{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim, A.sd_start, A.K,
-                      A.status, ws, ws + B * (N + 1), ws + B * (2 * N + 1), ws + B * (3 * N + 2)};
-        if (int rc = dispatch_sd_forward(A.d, F, stream)) return rc;
-        tpr::SdBlendArgs G{A.B, A.N, A.flags, atol, A.grid, ddes, F.xf, F.uf, F.xl, F.ul, A.status,
+        tpr::SdBlendArgs G{A.B, A.N, A.flags, atol, A.grid, ddes, xf, uf, xl, ul, A.status,
                            A.sd2, A.sd, A.u, dalpha, A.status};
-        hipLaunchKernelGGL(tpr::sd_blend_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, G);
+        const size_t finish_lds = 5 * (N + 1) * sizeof(double);
+        if (finish_lds <= kMaxDynamicLds) {
+            // one wave per trajectory: durations, bisection and the blend from LDS-resident profiles
+            hipLaunchKernelGGL(tpr::sd_finish_kernel, dim3(A.B), dim3(64), finish_lds, stream, G);
+        } else {
+            HIP_TRY(hipMemsetAsync(wlist + B, 0, sizeof(int32_t), stream));  // the worklist's counter sits behind it
+            hipLaunchKernelGGL(tpr::sd_decide_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, G, wlist, wlist + B);
+            hipLaunchKernelGGL(tpr::sd_bisect_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, G, wlist, wlist + B);
+            hipLaunchKernelGGL(tpr::sd_blend_kernel, dim3(A.B), dim3(64), 0, stream, G);
+        }
     }
     HIP_TRY(S.finish());
     return TPR_E_OK;
