@@ -299,11 +299,74 @@ def baseline_configs(torch, tb, dev):
     return res
 
 
+def end_to_end(torch, tb, dev, B=65536, d=7, N=200, samples=64):
+    """Waypoints -> q(t) with everything on the device, the headline shape (rank 0, N=1, outside the timed region):
+    tpr_spline_fit_batch (SplineInterpolator.__init__) -> tpr_solve_batch (compute_parameterization; sd only: what
+    retiming reads) -> tpr_param_spline_batch (ParametrizeSpline, the reference's default output parametrizer) ->
+    tpr_ppoly_eval_batch (q at `samples` times per trajectory).  Milliseconds per stage with HIP events on torch's
+    current stream (the library launches on it), median of 5; algorithmic bytes per stage beside them."""
+    rng = np.random.default_rng(20240924)
+    way = torch.from_numpy(rng.standard_normal((B, 5, d))).to(dev)
+    knots = torch.linspace(0, 1, 5, dtype=torch.float64, device=dev)
+    grid = torch.linspace(0, 1, N + 1, dtype=torch.float64, device=dev)
+    vlim_ = 10 + 20 * rng.random((B, d))
+    alim_ = 10 + 2 * rng.random((B, d))
+    vlim = torch.from_numpy(np.stack((-vlim_, vlim_), axis=-1)).to(dev)
+    alim = torch.from_numpy(np.stack((-alim_, alim_), axis=-1)).to(dev)
+    state = {}
+
+    def fit():
+        state["coef"], state["breaks"] = tb.spline_fit_batch(knots, way)
+
+    def solve():
+        state["sol"] = tb.solve_batch(state["coef"], state["breaks"], grid, vlim, alim, want_sd=True, want_K=False, want_u=False)
+
+    def param():
+        state["sp"] = tb.param_spline_batch(state["coef"], state["breaks"], grid, state["sol"]["sd"])
+
+    def evaluate():
+        sp = state["sp"]
+        dur = sp["knot_times"].gather(1, (sp["counts"].long() - 1).clamp(min=0).unsqueeze(1))
+        state["times"] = torch.linspace(0, 1, samples, dtype=torch.float64, device=dev).unsqueeze(0) * dur
+        state["q"] = tb.ppoly_eval_batch(sp["coef"], sp["knot_times"], state["times"], 0, sp["counts"])
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    nseg = 4
+    stages = {}
+    for name, fn, nbytes in (
+            ("spline_fit", fit, 8 * (B * 5 * d + B * 4 * nseg * d)),
+            ("solve_sd_only", solve, B * (8 * (4 * nseg * d + 4 * d) + 8 * 2 * (N + 1) + 4)),
+            ("param_spline", param, 8 * B * ((N + 1) + 4 * nseg * d + 4 * N * d + (N + 1)) + 4 * B),
+            ("ppoly_eval_%d_samples" % samples, evaluate, 8 * B * (samples + samples * d) + 8 * B * 4 * N * d)):
+        ms = timed(fn)
+        stages[name] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / (ms * 1e-3) / 1e9}
+    total = sum(s["ms"] for s in stages.values())
+    ok = float((state["sol"]["status"] == 0).double().mean().item())
+    finite = bool(torch.isfinite(state["q"][state["sol"]["status"] == 0]).all().item())
+    return {"workload": "batch=%d, %d-DoF, 5 waypoints -> N=%d gridpoints -> %d samples of q(t) per trajectory; device-resident" % (B, d, N, samples),
+            "stages": stages, "total_ms": total, "trajectories_per_s": B / total * 1e3, "ok_fraction": ok, "q_finite_where_ok": finite,
+            "note": "param_spline writes the [B, 4, N, d] coefficient table (%.2f GB): the one HBM-bound stage of the pipeline "
+                    "(6.3 TB/s achievable: MI355X_MICROARCH.md); ppoly_eval's bytes count the whole table although %d samples touch "
+                    "at most %d of its N segments" % (8 * B * 4 * N * d / 1e9, samples, samples)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
     ap.add_argument("--dof", type=int, default=7)
     ap.add_argument("--gridpoints", type=int, default=200, help="N (stages)")
@@ -315,6 +378,12 @@ def main():
     ap.add_argument("--rehearsal", action="store_true",
                     help="multi-rank control-flow rehearsal on ONE GPU: every rank uses cuda:0 and the gather runs over "
                          "gloo on host copies (RCCL refuses two ranks on one device); timings are meaningless")
+    ap.add_argument("--stub-solver", action="store_true",
+                    help="control-flow rehearsal WITHOUT a GPU (tests/test_distributed_gloo.py, world size 8 over gloo): "
+                         "the solve is replaced by a stub that tags sd^2 with (rank, step) so that rank 0 can check what "
+                         "the gather delivered; everything else -- gather placement calibration, pipelined gather, "
+                         "max-over-ranks timing, per-rank kernel times, the JSON line -- is the code of a real run.  "
+                         "Timings are meaningless")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs block (C1-C4, host-buffer path)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary (full iteration, family 2) measurements (used under rocprofv3 so that the "
@@ -323,14 +392,19 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from toppra_amd import build as hip_build
-    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        hip_build.ensure_built()  # no-op when the in-tree library travelled with the snapshot
+    stub = args.stub_solver
+    if stub:
+        args.rehearsal = True
+        args.no_secondary = args.no_configs = args.no_cpu_baseline = True
     else:
-        for _ in range(600):      # the other ranks wait for rank 0's build instead of racing it
-            if os.path.exists(hip_build.LIB):
-                break
-            time.sleep(0.5)
+        from toppra_amd import build as hip_build
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            hip_build.ensure_built()  # no-op when the in-tree library travelled with the snapshot
+        else:
+            for _ in range(600):      # the other ranks wait for rank 0's build instead of racing it
+                if os.path.exists(hip_build.LIB):
+                    break
+                time.sleep(0.5)
     from toppra_amd import batch as tb
 
     rank = int(os.environ.get("RANK", "0"))
@@ -341,8 +415,13 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if args.rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if stub:
+        dev = torch.device("cpu")
+        sync = lambda: None  # noqa: E731
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearsal:
@@ -352,10 +431,21 @@ def main():
     cdev = torch.device("cpu") if (args.rehearsal and world > 1) else dev  # where collectives run
 
     B, d, N = args.batch, args.dof, args.gridpoints
-    data = tb.make_synthetic_batch(B, d, N, seed=20240924 + rank)
-    nseg = data["coef"].shape[2]
-    dv = {k: torch.from_numpy(np.ascontiguousarray(data[k])).to(dev)
-          for k in ("coef", "breaks", "grid", "vlim", "alim")}
+    if stub:
+        nseg, dv, data = 4, None, None
+    else:
+        data = tb.make_synthetic_batch(B, d, N, seed=20240924 + rank)
+        nseg = data["coef"].shape[2]
+        dv = {k: torch.from_numpy(np.ascontiguousarray(data[k])).to(dev)
+              for k in ("coef", "breaks", "grid", "vlim", "alim")}
+    stub_step = {"n": 0}
+
+    def solve_once():
+        if stub:  # sd^2 tagged with (rank, step): what rank 0 must find in its receive buffers after the gather
+            stub_step["n"] += 1
+            tag = float(1000 * rank + stub_step["n"])
+            return {"sd2": torch.full((B, N + 1), tag, dtype=torch.float64), "status": torch.zeros(B, dtype=torch.int32), "tag": tag}
+        return tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], variant=args.variant)
 
     # N > 1: the only communication is the gather of sd^2 to rank 0 (RCCL); it is issued asynchronously so
     # that step k's gather rides the xGMI links while step k+1 is being solved (toppra_amd/distributed.py)
@@ -371,7 +461,7 @@ def main():
     gather_mode = {"value": "overlap" if args.gather == "auto" else args.gather}
 
     def step():
-        out = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], variant=args.variant)
+        out = solve_once()
         if gatherer is not None:
             gatherer.submit(out["sd2"].to(cdev))
             if gather_mode["value"] == "sequential":
@@ -381,10 +471,10 @@ def main():
     def fence():
         if gatherer is not None:
             gatherer.finish()  # the last step's gather is inside the timed region
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     out = None
     calibration = None
@@ -419,9 +509,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    gather_check = None
+    if stub and gatherer is not None and rank == 0:
+        # after the last fence the receive buffers hold every rank's LAST step: tag = 1000 r + (number of steps it ran)
+        bufs = gatherer.bufs
+        gather_check = all(bool((bufs[r] == float(1000 * r + stub_step["n"])).all()) for r in range(world))
     # dominant kernel: average launch duration with HIP events on the launch stream
-    kernel_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], out,
-                                     reps=args.kernel_reps, variant=args.variant)
+    if stub:
+        kernel_ms = 1.0 + 0.01 * rank
+    else:
+        kernel_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], out,
+                                         reps=args.kernel_reps, variant=args.variant)
     # secondary (single-GPU kernel times, not the headline): the reference's full Seidel iteration for
     # every LP (TPR_STRICT_SEIDEL, kernel family 2) and family 2 with its certified shortcuts; the
     # default path must return the same bits as the full iteration
@@ -447,12 +545,12 @@ def main():
         per_rank_kernel_ms = [float(v) for v in t.tolist()]
         g2 = PipelinedGather(B, N + 1, torch.float64, cdev)
         sd2c = out["sd2"].to(cdev)
-        g2.submit(sd2c); g2.finish(); torch.cuda.synchronize(); dist.barrier()
+        g2.submit(sd2c); g2.finish(); sync(); dist.barrier()
         t0 = time.perf_counter()
         for _ in range(5):
             g2.submit(sd2c)
             g2.finish()
-        torch.cuda.synchronize()
+        sync()
         tg = torch.tensor([(time.perf_counter() - t0) / 5 * 1e3], dtype=torch.float64, device=cdev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather_alone_ms = float(tg.item())
@@ -461,7 +559,7 @@ def main():
         bytes_per_traj = algorithmic_bytes(d, N, nseg)
         achieved = bytes_per_traj * B / (kernel_ms * 1e-3) / 1e9
         traj_per_s = world * B * args.steps / elapsed
-        pmc = pmc_traffic(B, d, N, kernel_ms)
+        pmc = None if stub else pmc_traffic(B, d, N, kernel_ms)
         line = {
             "metric": "trajectories/sec (7-DoF N=200 batch; waypoint-LPs/sec = 3N x this)",
             "value": traj_per_s,
@@ -480,7 +578,8 @@ def main():
                             "JointVelocity+JointAcceleration(Interpolation), seidel path, fp64" % (B, d, N),
                 "global_batch": world * B, "dof": d, "gridpoints": N,
                 "parallelism": ("shard%d+rccl_gather(sd2, %s)" % (world, gather_mode["value"]) if world > 1 else "single")
-                               + (" [REHEARSAL on one GPU over gloo: timings meaningless]" if args.rehearsal else ""),
+                               + (" [STUB SOLVER, no GPU: control-flow rehearsal over gloo, timings meaningless]" if stub else
+                                  (" [REHEARSAL on one GPU over gloo: timings meaningless]" if args.rehearsal else "")),
                 "kernel_variant": args.variant,
             },
             "waypoint_lps_per_s": 3 * N * traj_per_s,
@@ -519,10 +618,13 @@ def main():
             },
             "roofline_compute": compute_roofline(pmc, kernel_ms),
         }
+        if stub:
+            line["stub_gather_delivered_every_ranks_last_step"] = gather_check
         if not args.no_secondary and world == 1:
             line["tolerance_build"] = tolerance_probe(B, d, N, 20240924 + rank, out["sd2"].cpu().numpy(), out["status"].cpu().numpy())
         if not args.no_configs and world == 1:
             line["configs"] = baseline_configs(torch, tb, dev)
+            line["end_to_end"] = end_to_end(torch, tb, dev)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0's host cores)
             line["cpu_baseline"] = cpu_baseline(data)
         print(json.dumps(line))
