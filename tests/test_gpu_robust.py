@@ -133,3 +133,21 @@ def test_reference_qualitative_test(gpu, seed):
     assert np.all(K >= 0) and not np.any(np.isnan(K))
     traj = inst.compute_trajectory(0, 0)
     assert traj is not None and 0 < traj.duration < 20
+
+
+@pytest.mark.parametrize("B,d,N", [(300, 7, 40), (96, 12, 24), (64, 16, 16)])
+def test_rows_across_lanes_serves_every_case_with_the_lane_kernels_bits(gpu, B, d, N):
+    """Round 3: the rows-across-lanes robust kernel takes Collocation, feasible sets and 9..16 dof as well (the generic
+    lane kernel with its 4 KB of scratch rows is left with > 16 dof and very long spline tables): bit-identical to the
+    lane kernel (variant=1) in every combination."""
+    data = batch.make_synthetic_batch(B, d, N, seed=40 + d)
+    rng = np.random.default_rng(d)
+    sd1 = np.where(rng.random(B) < 0.3, 0.3 * rng.random(B), 0.0)
+    ell = [1e-3, 5e-2, 9e-3]
+    for vlim, kw in ((data["vlim"], dict()), (data["vlim"], dict(want_X=True)), (data["vlim"], dict(interpolation=False, want_X=True, sd_end=sd1)),
+                     (None, dict(want_X=True))):
+        args = (data["coef"], data["breaks"], data["grid"], vlim, data["alim"], ell)
+        want = batch.robust_solve_batch(*args, variant=1, **kw)
+        got = batch.robust_solve_batch(*args, **kw)
+        for k in want:
+            assert np.array_equal(got[k], want[k], equal_nan=True), (k, kw)

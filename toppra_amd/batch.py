@@ -115,14 +115,15 @@ def solve_desired_duration_batch(coef, breaks, grid, vlim, alim, desired_duratio
 
 
 def robust_solve_batch(coef, breaks, grid, vlim, alim, ellipsoid, sd_start=None, sd_end=None, interpolation=True,
-                       want_X=False):
+                       want_X=False, variant=0):
     """Robust TOPP-RA for B trajectories (``RobustLinearConstraint`` on the acceleration limits with
     perturbation ellipsoid ``(ru, rx, rc)``; BASELINE config 4).  PARITY UNPINNED against ECOS (absent here; the
     reference holds no golden vectors for it), cross-checked at 1e-7 against an independent exact solver
     (tests/test_gpu_robust.py): the reference solves these second-order-cone stage
-    problems with ECOS; this solves the same problems exactly (see csrc/tpr_robust.hip.inc).  Returns dict(sd2, sd, u, K, status[, X])."""
+    problems with ECOS; this solves the same problems exactly (see csrc/tpr_robust.hip.inc).  Returns dict(sd2, sd, u, K, status[, X]).
+    ``variant``: 0 = auto (rows across lanes up to 16 dof), 1 = the generic one-trajectory-per-lane kernel -- same bits."""
     _prepare(coef)
-    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation, variant=variant)
     B, N = p.B, p.N
     ell = np.ascontiguousarray(np.asarray(ellipsoid, dtype=np.float64).reshape(3))  # always a host array
     out = {"sd2": _empty(coef, (B, N + 1)), "sd": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)),

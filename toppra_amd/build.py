@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtoppra_hip.so")
-SOURCES = ["tpr_kernels.hip", "tpr_cert_tu.hip"]
+SOURCES = ["tpr_kernels.hip", "tpr_cert_tu.hip", "tpr_robust_tu.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
@@ -63,6 +63,9 @@ def _compile_and_link(target, flags, defines, verbose, single_tu):
         jobs = [(main, os.path.join(tmp, "main.o"), [])]
         for d in CERT_DOFS:
             jobs.append((os.path.join(CSRC, "tpr_cert_tu.hip"), os.path.join(tmp, "cert%d.o" % d), ["-DTPR_TU_D=%d" % d]))
+        for half in (0, 1):  # the robust (conic) kernels: 1..8 dof + the lane kernel, 9..16 dof
+            jobs.append((os.path.join(CSRC, "tpr_robust_tu.hip"), os.path.join(tmp, "robust%d.o" % half), ["-DTPR_TU_HALF=%d" % half]))
+        jobs.sort(key=lambda j: 0 if "robust" in j[1] else 1)  # the longest units first
 
         def run(job):
             src, obj, extra = job

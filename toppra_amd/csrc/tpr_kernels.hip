@@ -18,15 +18,21 @@
 #include "tpr_wave.hip.inc"
 #include "tpr_spline.hip.inc"
 #include "tpr_param.hip.inc"
-#include "tpr_robust.hip.inc"
+#include "tpr_robust_args.hpp"
 
 // kernel family 3, one translation unit per dof (tpr_cert_tu.hip)
 #ifdef TPR_SINGLE_TU  // development builds with instrumentation: everything in this translation unit, 7 dof only
 #define TPR_TU_D 7
 #include "tpr_cert_tu.hip"
 #undef TPR_TU_D
+#define TPR_TU_HALF 2
+#include "tpr_robust_tu.hip"
+#undef TPR_TU_HALF
 #else
 extern "C" {
+__attribute__((visibility("hidden"))) int tpr_tu_robust_launch_lo(const tpr::RobustArgs *, size_t, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_robust_launch_hi(const tpr::RobustArgs *, size_t, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_robust_lane_launch(const tpr::RobustArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_1(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_1(const tpr::GroupArgs *, double *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_1(const tpr::GroupArgs *, hipStream_t);
@@ -371,36 +377,12 @@ int dispatch_group_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stre
     return fail(TPR_E_UNSUPPORTED, "dof out of range");
 }
 
-template <int D>
-int launch_group_robust(const tpr::RobustArgs &P, hipStream_t stream) {
-    constexpr int L = 8;
-    const tpr::BatchArgs &A = P.A;
-    if (group_lds_bytes<D, L>(A.nseg, 64, true) > kMaxDynamicLds) {  // very long spline tables: lane kernel
-        hipLaunchKernelGGL(tpr::robust_solve_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, P);
-        return TPR_E_OK;
-    }
-    int threads = 64;
-    for (int t = 256; t > 64; t /= 2)
-        if (group_lds_bytes<D, L>(A.nseg, t, true) <= kMaxDynamicLds) { threads = t; break; }
-    while (threads > 64 && (long long)A.B * L / threads < 4 * 256) threads /= 2;
-    const int groups = threads / L;
-    const size_t lds = group_lds_bytes<D, L>(A.nseg, threads, true);
-    hipLaunchKernelGGL((tpr::group_robust_kernel<D, L>), dim3((A.B + groups - 1) / groups), dim3(threads), lds, stream, P);
-    return TPR_E_OK;
-}
-
+// The robust (conic) kernels live in their own translation units (tpr_robust_tu.hip): 0 = launched, 1 = the shape needs
+// the generic lane kernel (very long spline tables), -1 = dof not served.
 int dispatch_group_robust(const tpr::RobustArgs &P, hipStream_t stream) {
-    switch (P.A.d) {
-        case 1: return launch_group_robust<1>(P, stream);
-        case 2: return launch_group_robust<2>(P, stream);
-        case 3: return launch_group_robust<3>(P, stream);
-        case 4: return launch_group_robust<4>(P, stream);
-        case 5: return launch_group_robust<5>(P, stream);
-        case 6: return launch_group_robust<6>(P, stream);
-        case 7: return launch_group_robust<7>(P, stream);
-        case 8: return launch_group_robust<8>(P, stream);
-    }
-    return fail(TPR_E_UNSUPPORTED, "dof out of range");
+    int rc = P.A.d <= 8 ? tpr_tu_robust_launch_lo(&P, kMaxDynamicLds, stream) : tpr_tu_robust_launch_hi(&P, kMaxDynamicLds, stream);
+    if (rc == 1) rc = tpr_tu_robust_lane_launch(&P, stream);
+    return rc < 0 ? fail(TPR_E_UNSUPPORTED, "dof out of range") : TPR_E_OK;
 }
 
 // Family 4 (one trajectory per wave): every constraint set, every dof; grid, x box and K of the trajectory must
@@ -744,10 +726,11 @@ int tpr_robust_solve_batch(const tpr_problem *p, const double *ellipsoid, const 
     P.ru = ellipsoid[0]; P.rx = ellipsoid[1]; P.rc = ellipsoid[2];
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (P.A.B > 0) {
-        if (!P.X && group_supported(P.A) && interp_rows(P.A) && P.A.d <= 8) {  // rows across lanes; feasible sets / Collocation: lane kernel
+        // p->variant: 0 = auto, 1 = the generic lane kernel (one trajectory per lane, rows in scratch), 2 = rows across lanes
+        if (p->variant != 1 && group_supported(P.A)) {  // up to 16 dof, Interpolation or Collocation, with or without feasible sets
             if (int rc = dispatch_group_robust(P, stream)) return rc;
         } else {
-            hipLaunchKernelGGL(tpr::robust_solve_kernel, dim3((P.A.B + 63) / 64), dim3(64), 0, stream, P);
+            (void)tpr_tu_robust_lane_launch(&P, stream);
         }
     }
     HIP_TRY(S.finish());
