@@ -155,3 +155,30 @@ def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
     X = batch.feasible_sets_batch(data["coef"][:64], data["breaks"], data["grid"], None if vlim is None else vlim[:64],
                                   None if alim is None else alim[:64], interp)
     assert X.shape == (64, N + 1, 2) and not np.isnan(X).any()
+
+
+@pytest.mark.parametrize("d", [9, 10, 11, 12])
+def test_certified_lane_kernel_above_8_dof(gpu, d):
+    """Round 3: family 3 serves 9..12 dof too (internal row numbering with a block stride of 16): solve (fast and sound
+    certificates, scaled paths, boundary velocities, Collocation), feasible sets and TOPPRAsd against the rows-across-lanes
+    kernels -- the full iteration where there is a strict mode -- bit for bit."""
+    B, N = 1200, 50
+    data = batch.make_synthetic_batch(B, d, N, seed=60 + d)
+    rng = np.random.default_rng(d)
+    scale = np.where(rng.random((B, 1, 1, 1)) < 0.5, 1.0, 10.0 ** rng.uniform(-6, 0, size=(B, 1, 1, 1)))
+    sd0 = np.where(rng.random(B) < 0.3, 0.1 * rng.random(B), 0.0)
+    sd1 = np.where(rng.random(B) < 0.3, 0.3 * rng.random(B), 0.0)
+    for interp in (True, False):
+        args = (data["coef"] * scale, data["breaks"], data["grid"], data["vlim"], data["alim"], sd0, sd1, interp)
+        full = batch.solve_batch(*args, variant=2, strict=True)
+        for sound in (False, True):
+            got = batch.solve_batch(*args, variant=3, sound=sound)
+            for k in ("K", "sd2", "u", "status"):
+                assert np.array_equal(got[k], full[k], equal_nan=True), (k, interp, sound)
+        fargs = args[:5] + (interp,)
+        assert np.array_equal(batch.feasible_sets_batch(*fargs, variant=3), batch.feasible_sets_batch(*fargs, variant=2, strict=True), equal_nan=True)
+        desired = rng.uniform(0.3, 6.0, size=B)
+        want = batch.solve_desired_duration_batch(*args[:5], desired, sd0, sd1, variant=2, interpolation=interp)
+        got = batch.solve_desired_duration_batch(*args[:5], desired, sd0, sd1, variant=3, interpolation=interp)
+        for k in ("K", "sd2", "u", "status", "alpha"):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (k, interp)

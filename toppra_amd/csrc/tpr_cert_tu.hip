@@ -31,7 +31,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_laun
     const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
     const size_t static_lds = (((6 * D + 6) > 24 ? (6 * D + 6) : 24) * BS + tpr::kCertXch * BS +
                                tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
-    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && static_lds + grid_bytes <= 40 * 1024;
+    // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
+    // wave per SIMD --, three at 9..11 dof, two above)
+    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
     const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
     // One 64-lane block per wave; ~39 KB of LDS per block leaves one wave per SIMD, which the kernel
@@ -58,7 +60,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feas
     const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
     const size_t static_lds = (((6 * D + 6) > 24 ? (6 * D + 6) : 24) * BS + tpr::kCertXch * BS +
                                tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
-    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && static_lds + grid_bytes <= 40 * 1024;
+    // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
+    // wave per SIMD --, three at 9..11 dof, two above)
+    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
     const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
     const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;
@@ -79,7 +83,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_l
     const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
     const size_t cols = ((6 * D + 6) > 32 ? (6 * D + 6) : 32) * BS;
     const size_t static_lds = (cols + tpr::kCertXch * BS + tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
-    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && static_lds + grid_bytes <= 40 * 1024;
+    // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
+    // wave per SIMD --, three at 9..11 dof, two above)
+    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
     const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
     const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;

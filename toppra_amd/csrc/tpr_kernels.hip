@@ -20,7 +20,10 @@
 #include "tpr_param.hip.inc"
 #include "tpr_robust_args.hpp"
 
-// kernel family 3, one translation unit per dof (tpr_cert_tu.hip)
+// kernel family 3, one translation unit per dof (tpr_cert_tu.hip): 1..TPR_CERT_MAX_DOF (build.py: 16)
+#ifndef TPR_CERT_MAX_DOF
+#define TPR_CERT_MAX_DOF 8
+#endif
 #ifdef TPR_SINGLE_TU  // development builds with instrumentation: everything in this translation unit, 7 dof only
 #define TPR_TU_D 7
 #include "tpr_cert_tu.hip"
@@ -57,6 +60,46 @@ __attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_7(const tpr::Gro
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_8(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_8(const tpr::GroupArgs *, double *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_8(const tpr::GroupArgs *, hipStream_t);
+#if TPR_CERT_MAX_DOF >= 9
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_9(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_9(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_9(const tpr::GroupArgs *, hipStream_t);
+#endif
+#if TPR_CERT_MAX_DOF >= 10
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_10(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_10(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_10(const tpr::GroupArgs *, hipStream_t);
+#endif
+#if TPR_CERT_MAX_DOF >= 11
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_11(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_11(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_11(const tpr::GroupArgs *, hipStream_t);
+#endif
+#if TPR_CERT_MAX_DOF >= 12
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_12(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_12(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_12(const tpr::GroupArgs *, hipStream_t);
+#endif
+#if TPR_CERT_MAX_DOF >= 13
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_13(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_13(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_13(const tpr::GroupArgs *, hipStream_t);
+#endif
+#if TPR_CERT_MAX_DOF >= 14
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_14(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_14(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_14(const tpr::GroupArgs *, hipStream_t);
+#endif
+#if TPR_CERT_MAX_DOF >= 15
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_15(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_15(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_15(const tpr::GroupArgs *, hipStream_t);
+#endif
+#if TPR_CERT_MAX_DOF >= 16
+__attribute__((visibility("hidden"))) int tpr_tu_cert_launch_16(const tpr::GroupArgs *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_16(const tpr::GroupArgs *, double *, hipStream_t);
+__attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_16(const tpr::GroupArgs *, hipStream_t);
+#endif
 }
 #endif
 
@@ -273,7 +316,7 @@ int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
 // The certified lane kernel (family 3) serves the same constraint set up to 8 dof when sd2, u and
 // status are requested; the strict mode stays with family 2.
 bool cert_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= 8 && !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
+    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= TPR_CERT_MAX_DOF && !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
            (A.backward_only || (A.sd2 && A.u && A.status));
 }
 
@@ -290,6 +333,30 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
         case 5: return tpr_tu_cert_launch_5(&G, stream);
         case 6: return tpr_tu_cert_launch_6(&G, stream);
         case 8: return tpr_tu_cert_launch_8(&G, stream);
+#if TPR_CERT_MAX_DOF >= 9
+        case 9: return tpr_tu_cert_launch_9(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 10
+        case 10: return tpr_tu_cert_launch_10(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 11
+        case 11: return tpr_tu_cert_launch_11(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 12
+        case 12: return tpr_tu_cert_launch_12(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 13
+        case 13: return tpr_tu_cert_launch_13(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 14
+        case 14: return tpr_tu_cert_launch_14(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 15
+        case 15: return tpr_tu_cert_launch_15(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 16
+        case 16: return tpr_tu_cert_launch_16(&G, stream);
+#endif
 #endif
         case 7: return tpr_tu_cert_launch_7(&G, stream);
     }
@@ -298,7 +365,7 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
 
 // compute_feasible_sets on the certified lane design: the constraint sets and dofs of family 3, fresh warm-start state
 bool cert_feasible_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= 8 && !(A.flags & TPR_STRICT_SEIDEL) && !A.active;
+    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= TPR_CERT_MAX_DOF && !(A.flags & TPR_STRICT_SEIDEL) && !A.active;
 }
 
 int launch_cert_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream) {
@@ -313,6 +380,30 @@ int launch_cert_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream)
         case 5: return tpr_tu_cert_feasible_launch_5(&G, X, stream);
         case 6: return tpr_tu_cert_feasible_launch_6(&G, X, stream);
         case 8: return tpr_tu_cert_feasible_launch_8(&G, X, stream);
+#if TPR_CERT_MAX_DOF >= 9
+        case 9: return tpr_tu_cert_feasible_launch_9(&G, X, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 10
+        case 10: return tpr_tu_cert_feasible_launch_10(&G, X, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 11
+        case 11: return tpr_tu_cert_feasible_launch_11(&G, X, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 12
+        case 12: return tpr_tu_cert_feasible_launch_12(&G, X, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 13
+        case 13: return tpr_tu_cert_feasible_launch_13(&G, X, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 14
+        case 14: return tpr_tu_cert_feasible_launch_14(&G, X, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 15
+        case 15: return tpr_tu_cert_feasible_launch_15(&G, X, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 16
+        case 16: return tpr_tu_cert_feasible_launch_16(&G, X, stream);
+#endif
 #endif
         case 7: return tpr_tu_cert_feasible_launch_7(&G, X, stream);
     }
@@ -332,6 +423,30 @@ int launch_cert_sd(const tpr::BatchArgs &A, double *xf, double *uf, double *xl, 
         case 5: return tpr_tu_cert_sd_launch_5(&G, stream);
         case 6: return tpr_tu_cert_sd_launch_6(&G, stream);
         case 8: return tpr_tu_cert_sd_launch_8(&G, stream);
+#if TPR_CERT_MAX_DOF >= 9
+        case 9: return tpr_tu_cert_sd_launch_9(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 10
+        case 10: return tpr_tu_cert_sd_launch_10(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 11
+        case 11: return tpr_tu_cert_sd_launch_11(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 12
+        case 12: return tpr_tu_cert_sd_launch_12(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 13
+        case 13: return tpr_tu_cert_sd_launch_13(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 14
+        case 14: return tpr_tu_cert_sd_launch_14(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 15
+        case 15: return tpr_tu_cert_sd_launch_15(&G, stream);
+#endif
+#if TPR_CERT_MAX_DOF >= 16
+        case 16: return tpr_tu_cert_sd_launch_16(&G, stream);
+#endif
 #endif
         case 7: return tpr_tu_cert_sd_launch_7(&G, stream);
     }
@@ -423,7 +538,9 @@ int pick_variant(int requested, const tpr::BatchArgs &A) {
     // fixed-latency round, which beats family 2's throughput from about a quarter of that batch upward
     // (tools/gpu_crossover.py); family 2 serves the strict mode and what is left.
     if (wave_supported(A) && A.B <= TPR_WAVE_AUTO_MAX_BATCH) return 4;
-    if (cert_supported(A) && A.B >= 14336) return 3;
+    // (9..12 dof: family 3 fits three blocks per CU -- 49152 trajectories per round -- at 1.9 .. 2.9 ms a round against
+    // family 2's 7.7 .. 8.7 ms per 65536: tools/gpu_cert_dofs_check.py)
+    if (cert_supported(A) && A.B >= (A.d <= 8 ? 14336 : 24576)) return 3;
     return group_supported(A) ? 2 : (wave_supported(A) ? 4 : 1);
 }
 
@@ -437,7 +554,7 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
         }
         case 3: {
             if (!cert_supported(A))
-                return fail(TPR_E_UNSUPPORTED, "variant 3 needs acceleration+interpolation, d <= 8, sd2/u/status outputs, default mode");
+                return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 12, sd2/u/status outputs, default mode");
             return launch_cert(A, stream);
         }
         case 2: {
@@ -674,10 +791,10 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
         tpr::BatchArgs Ab = A;
         Ab.backward_only = 1;
         // p->variant: 0 = auto; 2 / 3 force the rows-across-lanes scans / the certified lane kernel for both scans
-        const bool fused = p->variant == 3 || (p->variant == 0 && cert_supported(Ab) && A.B >= 14336);
+        const bool fused = p->variant == 3 || (p->variant == 0 && cert_supported(Ab) && A.B >= (A.d <= 8 ? 14336 : 24576));
         if (fused) {
             // family 3: backward scan + fastest / slowest forward profiles in ONE launch (cert_solve_kernel<SDFWD>)
-            if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 8, default mode");
+            if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 12, default mode");
             if (int rc = launch_cert_sd(A, xf, uf, xl, ul, stream)) return rc;
         } else {
             // backward scan -> K and the controllability verdict (the time-optimal forward scan is not needed), then
@@ -836,14 +953,14 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
         const int want = p->variant;
         const bool wave_auto = wave_supported(A) && (A.active || A.B <= 64 || !group_supported(A));
         if (want == 3 && !cert_feasible_supported(A))
-            return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 8, default mode, no warm-start state");
+            return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 12, default mode, no warm-start state");
         if (want == 4 && !wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables");
         if (want == 4 || (want == 0 && wave_auto)) {
             // one trajectory per wave: a handful of trajectories (latency), 17..32 dof, or the wrapper object's
             // warm-start state in / out
             A.feasible_X = dX;
             if (int rc = launch_wave(A, stream)) return rc;
-        } else if (want == 3 || (want == 0 && cert_feasible_supported(A) && A.B >= 8192)) {
+        } else if (want == 3 || (want == 0 && cert_feasible_supported(A) && A.B >= (A.d <= 8 ? 8192 : 24576))) {
             // one trajectory per lane, certified answers (family 3): a fixed-latency round up to 65536 trajectories
             if (int rc = launch_cert_feasible(A, dX, stream)) return rc;
         } else if (group_supported(A) && want != 1) {
