@@ -49,8 +49,10 @@ def main():
         "family2_strict_65536x7x200": lambda: tb.solve_batch(*dv, variant=2, strict=True),
         "family4_4096x7x200": None,
         "feasible_sets_65536x7x200": lambda: tb.feasible_sets_batch(*dv),
+        "feasible_sets_family2_65536x7x200": lambda: tb.feasible_sets_batch(*dv, variant=2),
         "controllable_sets_65536x7x200": lambda: tb.controllable_sets_batch(*dv, zero, zero),
         "toppra_sd_65536x7x200": lambda: tb.solve_desired_duration_batch(*dv, 3.0),
+        "toppra_sd_family2_65536x7x200": lambda: tb.solve_desired_duration_batch(*dv, 3.0, variant=2),
     }
     d2 = tb.make_synthetic_batch(4096, 7, 200)
     dv2 = dev_args(d2)
@@ -61,6 +63,9 @@ def main():
     d12 = tb.make_synthetic_batch(65536, 12, 200)
     dv12 = dev_args(d12)
     cases["family2_default_65536x12x200"] = lambda: tb.solve_batch(*dv12, variant=2)
+    cases["family3_65536x12x200"] = lambda: tb.solve_batch(*dv12)
+    cases["robust_collocation_16384x7x100"] = lambda: tb.robust_solve_batch(*dv4, [1e-3, 5e-2, 9e-3], interpolation=False)
+    cases["robust_with_feasible_sets_16384x7x100"] = lambda: tb.robust_solve_batch(*dv4, [1e-3, 5e-2, 9e-3], want_X=True)
     # f1 / f2: spline fit of the waypoints, ParametrizeSpline of the result, evaluation
     rng = np.random.default_rng(1)
     way = torch.from_numpy(rng.standard_normal((B, 5, d))).to(dev)
