@@ -288,6 +288,9 @@ def baseline_configs(torch, tb, dev):
         "note": "RobustLinearConstraint over JointAcceleration, ellipsoid (1e-3, 5e-2, 9e-3); the reference's ECOS stage "
                 "problems solved exactly; parity unpinned against ECOS (absent), cross-checked at 1e-7 against an independent exact solver (tests/test_gpu_robust.py)"}
     res["C5_batch524288_8gpu"] = "this bench with --gpus 8 (65536 trajectories per rank + RCCL gather of sd^2)"
+    res["large_batch262144_d7_N200"] = dict(kernel(262144, 7, 200, reps=3),
+                                            note="four rounds of one wave per SIMD: the kernel has no two-waves-per-SIMD variant (DESIGN.md 3.8)")
+    res["d12_batch65536_N200"] = dict(kernel(65536, 12, 200, reps=3), note="kernel family 3 at 12 dof: three blocks per CU (DESIGN.md 3.2)")
     # PCIe-inclusive: numpy in -> numpy out through the host-buffer entry (H2D 59 MB, kernel, D2H)
     datah = tb.make_synthetic_batch(65536, 7, 200)
     hargs = [datah[k] for k in ("coef", "breaks", "grid", "vlim", "alim")]
@@ -523,7 +526,7 @@ def main():
     # secondary (single-GPU kernel times, not the headline): the reference's full Seidel iteration for
     # every LP (TPR_STRICT_SEIDEL, kernel family 2) and family 2 with its certified shortcuts; the
     # default path must return the same bits as the full iteration
-    strict_ms = family2_ms = same_bits = None
+    strict_ms = family2_ms = same_bits = sound_ms = sound_same = None
     if not args.no_secondary and world == 1:
         reps = max(2, args.kernel_reps // 2)
         full = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], strict=True)
@@ -533,6 +536,13 @@ def main():
                                          reps=reps, strict=True)
         family2_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], full,
                                           reps=reps, variant=2)
+        # the sound certificate mode of the default kernel (TPR_SOUND_CERTIFICATES)
+        snd = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], sound=True, variant=args.variant)
+        sound_same = all(bool(torch.equal(torch.nan_to_num(snd[k], nan=-7.0), torch.nan_to_num(full[k], nan=-7.0)))
+                         for k in ("sd2", "u", "K")) and bool(torch.equal(snd["status"], full["status"]))
+        sound_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], snd,
+                                        reps=reps, variant=args.variant, sound=True)
+        del snd
     ok_frac = float((out["status"] == 0).double().mean().item())
 
     # multi-GPU: what each rank's kernel took and what the gather costs on its own (outside the timed region),
@@ -593,6 +603,14 @@ def main():
                 "kernel_ms": strict_ms, "value_per_gpu": (B / strict_ms * 1e3) if strict_ms else None,
                 "unit": "trajectories/s",
                 "default_path_returns_identical_bits": same_bits,
+            },
+            "sound_certificates": {
+                "note": "TPR_SOUND_CERTIFICATES: the default kernel certifying a MOVED active pair only where the reference's own "
+                        "pivot sequence is predictable (everything else through the full iteration); the default (fast) mode "
+                        "returns the LP's optimum on a stage where the reference itself fails on a 1e-14 sliver of an "
+                        "intermediate pivot -- 1 in 204800 adversarial trajectories, none in natural batches (DESIGN.md 3.1)",
+                "kernel_ms": sound_ms, "value_per_gpu": (B / sound_ms * 1e3) if sound_ms else None, "unit": "trajectories/s",
+                "identical_bits_to_full_iteration": sound_same,
             },
             "family2_rows_across_lanes": {
                 "note": "kernel family 2 (8 lanes per trajectory) with its certified shortcuts; serves d > 8 and the "

@@ -70,8 +70,8 @@ extern "C" {
  * 1e-10, a sliver of 1e-14 (tests/test_gpu_fullsize.py::test_concurrent_rows_and_sliver_pivots_are_bit_exact:
  * 1 in 1.5e5 trajectories of an adversarial family, ~1e-5 expected events per 65536 x 200 natural batch, none
  * observed in 4e9 stage LPs) -- and the fast mode then returns the LP's optimum where the reference reports failure.
- * Kernel family 4 (the latency kernel, which serves the drop-in class) is always sound.  Cost at the headline shape:
- * see DESIGN.md section 3.1.                                                                                        */
+ * Kernel family 4 (the latency kernel, which serves the drop-in class) is always sound.  Above 8 dof the flag is served
+ * by the rows-across-lanes kernels.  Cost at the headline shape: see DESIGN.md section 3.1.                                                                                        */
 #define TPR_SOUND_CERTIFICATES 512
 
 /* per-trajectory status == ParameterizationReturnCode (algorithm/algorithm.py:49-62) */

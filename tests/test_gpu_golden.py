@@ -36,7 +36,7 @@ def test_batch_fixture(gpu, name):
     if "X" in fx:
         assert_same(batch.feasible_sets_batch(coef, breaks, grid, vlim, alim, interp), fx["X"], "X")
         # ... and through every kernel family that serves it (3: the certified lane kernel, fast and sound certificates)
-        for kw in [dict(variant=2), dict(variant=4)] + ([dict(variant=3), dict(variant=3, sound=True)] if coef.shape[3] <= 12 and alim is not None else []):
+        for kw in [dict(variant=2), dict(variant=4)] + ([dict(variant=3)] if coef.shape[3] <= 12 and alim is not None else []) + ([dict(variant=3, sound=True)] if coef.shape[3] <= 8 and alim is not None else []):
             assert_same(batch.feasible_sets_batch(coef, breaks, grid, vlim, alim, interp, **kw), fx["X"], "X %s" % kw)
     # compute_controllable_sets(sd_end, sd_end) is the K of the parameterization
     K = batch.controllable_sets_batch(coef, breaks, grid, vlim, alim, sd1, sd1, interp)

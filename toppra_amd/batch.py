@@ -152,11 +152,13 @@ def solve_batch_timed(coef, breaks, grid, vlim, alim, out, reps, sd_start=None, 
     return float(ms.value)
 
 
-def controllable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpolation=True, active=None, squared=False):
+def controllable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpolation=True, active=None, squared=False,
+                            variant=0, strict=False, sound=False):
     """compute_controllable_sets(sdmin, sdmax) for B trajectories -> K[B,N+1,2] (``active``: see solve_batch;
-    ``squared``: sdmin / sdmax already hold sd^2 -- TPR_BOUNDARY_SQUARED)."""
+    ``squared``: sdmin / sdmax already hold sd^2 -- TPR_BOUNDARY_SQUARED; ``variant`` / ``strict`` / ``sound``: as solve_batch)."""
     _prepare(coef)
-    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation, active=active, squared=squared)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation, active=active, squared=squared,
+                                 variant=variant, strict=strict, sound=sound)
     sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, coef)
     sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, coef)
     K = _empty(coef, (p.B, p.N + 1, 2))

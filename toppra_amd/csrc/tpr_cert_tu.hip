@@ -17,6 +17,14 @@
 #error "compile with -DTPR_TU_D=<dof 1..8>"
 #endif
 
+// The sound certificate mode is instantiated up to 8 dof only: at 9..12 dof the sound instantiations returned lower bounds
+// that were off in the last bits on up to 0.9 % of an irregular batch (asymmetric limits, standing joints, non-uniform
+// grids: tools/gpu_r3_stress.py) -- only they, deterministically, and not once the source was perturbed by a debug store
+// or the grid read from global memory; the fast instantiations of the same dofs are bit-exact on 0.8 M trajectories of
+// both stress families.  Not understood; sound requests above 8 dof are served by the
+// rows-across-lanes kernels, whose sound mode is bit-exact there.  -2 = not instantiated.
+constexpr bool kSoundHere = TPR_TU_D <= 8;
+
 #define TPR_TU_CAT2(a, b) a##b
 #define TPR_TU_CAT(a, b) TPR_TU_CAT2(a, b)
 
@@ -33,13 +41,17 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_laun
                                tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
     // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
     // wave per SIMD --, three at 9..11 dof, two above)
-    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
+    // ... and only up to 8 dof: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
+    // were off in the last bits on 0.9 % of an irregular batch (tools/gpu_r3_stress.py) while the same source with the grid
+    // read from global memory, with fast certificates, or with one more debug store is bit-exact -- not understood
+    // (DESIGN.md section 4.1); above 8 dof the grid is read from global memory.
+    const bool grid_lds = D <= 8 && !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
     const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
     // One 64-lane block per wave; ~39 KB of LDS per block leaves one wave per SIMD, which the kernel
     // is written for (the whole register file, stalls covered by unrolled independent row work).
 #define TPR_LAUNCH_CERT(SD, GL, IN, SO) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, SD, GL, IN, SO>), grid, block, lds, stream, G)
-#define TPR_LAUNCH_CERT3(SD, GL, IN) do { if (sound) TPR_LAUNCH_CERT(SD, GL, IN, true); else TPR_LAUNCH_CERT(SD, GL, IN, false); } while (0)
+#define TPR_LAUNCH_CERT3(SD, GL, IN) do { if (sound) { if constexpr (kSoundHere) TPR_LAUNCH_CERT(SD, GL, IN, true); else return -2; } else TPR_LAUNCH_CERT(SD, GL, IN, false); } while (0)
     if (G.flags & TPR_ACC_INTERPOLATION) {
         if (G.sd) { if (grid_lds) TPR_LAUNCH_CERT3(true, true, true); else TPR_LAUNCH_CERT3(true, false, true); }
         else { if (grid_lds) TPR_LAUNCH_CERT3(false, true, true); else TPR_LAUNCH_CERT3(false, false, true); }
@@ -62,12 +74,16 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feas
                                tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
     // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
     // wave per SIMD --, three at 9..11 dof, two above)
-    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
+    // ... and only up to 8 dof: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
+    // were off in the last bits on 0.9 % of an irregular batch (tools/gpu_r3_stress.py) while the same source with the grid
+    // read from global memory, with fast certificates, or with one more debug store is bit-exact -- not understood
+    // (DESIGN.md section 4.1); above 8 dof the grid is read from global memory.
+    const bool grid_lds = D <= 8 && !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
     const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
     const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;
 #define TPR_LAUNCH_FEAS(GL, IN, SO) hipLaunchKernelGGL((tpr::cert_feasible_kernel<D, BS, GL, IN, SO>), grid, block, lds, stream, G, X)
-#define TPR_LAUNCH_FEAS2(GL, IN) do { if (sound) TPR_LAUNCH_FEAS(GL, IN, true); else TPR_LAUNCH_FEAS(GL, IN, false); } while (0)
+#define TPR_LAUNCH_FEAS2(GL, IN) do { if (sound) { if constexpr (kSoundHere) TPR_LAUNCH_FEAS(GL, IN, true); else return -2; } else TPR_LAUNCH_FEAS(GL, IN, false); } while (0)
     if (interp) { if (grid_lds) TPR_LAUNCH_FEAS2(true, true); else TPR_LAUNCH_FEAS2(false, true); }
     else { if (grid_lds) TPR_LAUNCH_FEAS2(true, false); else TPR_LAUNCH_FEAS2(false, false); }
 #undef TPR_LAUNCH_FEAS2
@@ -85,12 +101,16 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_l
     const size_t static_lds = (cols + tpr::kCertXch * BS + tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
     // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
     // wave per SIMD --, three at 9..11 dof, two above)
-    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
+    // ... and only up to 8 dof: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
+    // were off in the last bits on 0.9 % of an irregular batch (tools/gpu_r3_stress.py) while the same source with the grid
+    // read from global memory, with fast certificates, or with one more debug store is bit-exact -- not understood
+    // (DESIGN.md section 4.1); above 8 dof the grid is read from global memory.
+    const bool grid_lds = D <= 8 && !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
     const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
     const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;
 #define TPR_LAUNCH_SD(GL, IN, SO) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, false, GL, IN, SO, true>), grid, block, lds, stream, G)
-#define TPR_LAUNCH_SD2(GL, IN) do { if (sound) TPR_LAUNCH_SD(GL, IN, true); else TPR_LAUNCH_SD(GL, IN, false); } while (0)
+#define TPR_LAUNCH_SD2(GL, IN) do { if (sound) { if constexpr (kSoundHere) TPR_LAUNCH_SD(GL, IN, true); else return -2; } else TPR_LAUNCH_SD(GL, IN, false); } while (0)
     if (interp) { if (grid_lds) TPR_LAUNCH_SD2(true, true); else TPR_LAUNCH_SD2(false, true); }
     else { if (grid_lds) TPR_LAUNCH_SD2(true, false); else TPR_LAUNCH_SD2(false, false); }
 #undef TPR_LAUNCH_SD2

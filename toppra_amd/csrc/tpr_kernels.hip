@@ -20,12 +20,17 @@
 #include "tpr_param.hip.inc"
 #include "tpr_robust_args.hpp"
 
-// kernel family 3, one translation unit per dof (tpr_cert_tu.hip): 1..TPR_CERT_MAX_DOF (build.py: 16)
+#define TPR_TU_CAT3_(a, b) a##b
+#define TPR_TU_CAT3(a, b) TPR_TU_CAT3_(a, b)
+// kernel family 3, one translation unit per dof (tpr_cert_tu.hip): 1..TPR_CERT_MAX_DOF (build.py: 12)
 #ifndef TPR_CERT_MAX_DOF
 #define TPR_CERT_MAX_DOF 8
 #endif
-#ifdef TPR_SINGLE_TU  // development builds with instrumentation: everything in this translation unit, 7 dof only
-#define TPR_TU_D 7
+#ifdef TPR_SINGLE_TU  // development builds with instrumentation: everything in this translation unit, ONE dof for family 3 (7; -DTPR_SINGLE_TU_D=<dof>)
+#ifndef TPR_SINGLE_TU_D
+#define TPR_SINGLE_TU_D 7
+#endif
+#define TPR_TU_D TPR_SINGLE_TU_D
 #include "tpr_cert_tu.hip"
 #undef TPR_TU_D
 #define TPR_TU_HALF 2
@@ -316,7 +321,8 @@ int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
 // The certified lane kernel (family 3) serves the same constraint set up to 8 dof when sd2, u and
 // status are requested; the strict mode stays with family 2.
 bool cert_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= TPR_CERT_MAX_DOF && !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
+    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= ((A.flags & TPR_SOUND_CERTIFICATES) ? 8 : TPR_CERT_MAX_DOF) &&
+           !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
            (A.backward_only || (A.sd2 && A.u && A.status));
 }
 
@@ -357,15 +363,18 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
 #if TPR_CERT_MAX_DOF >= 16
         case 16: return tpr_tu_cert_launch_16(&G, stream);
 #endif
-#endif
         case 7: return tpr_tu_cert_launch_7(&G, stream);
+#else
+        case TPR_SINGLE_TU_D: return TPR_TU_CAT3(tpr_tu_cert_launch_, TPR_SINGLE_TU_D)(&G, stream);
+#endif
     }
     return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
 }
 
 // compute_feasible_sets on the certified lane design: the constraint sets and dofs of family 3, fresh warm-start state
 bool cert_feasible_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= TPR_CERT_MAX_DOF && !(A.flags & TPR_STRICT_SEIDEL) && !A.active;
+    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= ((A.flags & TPR_SOUND_CERTIFICATES) ? 8 : TPR_CERT_MAX_DOF) &&
+           !(A.flags & TPR_STRICT_SEIDEL) && !A.active;
 }
 
 int launch_cert_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream) {
@@ -404,8 +413,10 @@ int launch_cert_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream)
 #if TPR_CERT_MAX_DOF >= 16
         case 16: return tpr_tu_cert_feasible_launch_16(&G, X, stream);
 #endif
-#endif
         case 7: return tpr_tu_cert_feasible_launch_7(&G, X, stream);
+#else
+        case TPR_SINGLE_TU_D: return TPR_TU_CAT3(tpr_tu_cert_feasible_launch_, TPR_SINGLE_TU_D)(&G, X, stream);
+#endif
     }
     return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
 }
@@ -447,8 +458,10 @@ int launch_cert_sd(const tpr::BatchArgs &A, double *xf, double *uf, double *xl, 
 #if TPR_CERT_MAX_DOF >= 16
         case 16: return tpr_tu_cert_sd_launch_16(&G, stream);
 #endif
-#endif
         case 7: return tpr_tu_cert_sd_launch_7(&G, stream);
+#else
+        case TPR_SINGLE_TU_D: return TPR_TU_CAT3(tpr_tu_cert_sd_launch_, TPR_SINGLE_TU_D)(&G, stream);
+#endif
     }
     return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
 }
@@ -554,7 +567,7 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
         }
         case 3: {
             if (!cert_supported(A))
-                return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 12, sd2/u/status outputs, default mode");
+                return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 12 (8 with sound certificates), sd2/u/status outputs, no strict mode");
             return launch_cert(A, stream);
         }
         case 2: {
@@ -794,7 +807,7 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
         const bool fused = p->variant == 3 || (p->variant == 0 && cert_supported(Ab) && A.B >= (A.d <= 8 ? 14336 : 24576));
         if (fused) {
             // family 3: backward scan + fastest / slowest forward profiles in ONE launch (cert_solve_kernel<SDFWD>)
-            if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 12, default mode");
+            if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 12 (8 with sound certificates), no strict mode");
             if (int rc = launch_cert_sd(A, xf, uf, xl, ul, stream)) return rc;
         } else {
             // backward scan -> K and the controllability verdict (the time-optimal forward scan is not needed), then
@@ -953,7 +966,7 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
         const int want = p->variant;
         const bool wave_auto = wave_supported(A) && (A.active || A.B <= 64 || !group_supported(A));
         if (want == 3 && !cert_feasible_supported(A))
-            return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 12, default mode, no warm-start state");
+            return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 12 (8 with sound certificates), no strict mode, no warm-start state");
         if (want == 4 && !wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables");
         if (want == 4 || (want == 0 && wave_auto)) {
             // one trajectory per wave: a handful of trajectories (latency), 17..32 dof, or the wrapper object's
