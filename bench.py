@@ -84,7 +84,7 @@ def compute_roofline(pmc, kernel_ms):
             "instruction_count_source": pmc["source"] + " -- REPLAYED, not measured in this run; kernel_ms is this run's",
             "note": "every lane-instruction of this kernel is an fp64 / integer VALU operation of a 64-wide wave (no MFMA: the "
                     "path has no dense contraction); one wave per SIMD, so the issue rate is additionally capped by the "
-                    "single-wave issue interval (~5 cycles per instruction of any kind: profiles/r02_single_wave_issue_microbench.log)"}
+                    "single-wave issue interval (~5 cycles per instruction of any kind: profiles/r02_single_wave_issue_microbench.log, round 2)"}
 
 
 def cpu_baseline(data, target_seconds=12.0):
@@ -175,7 +175,7 @@ def cpu_baseline(data, target_seconds=12.0):
             "reference_itself": {
                 "value": 180.0, "unit": "trajectories/s per core", "where": "build container, 1 core, Python+Cython seidel",
                 "note": "the reference cannot run on the GPU box: /root/reference is absent there and its sources may not be "
-                        "copied into this repository, so the timed baseline is the C port (which is ~25x faster per core "
+                        "copied into this repository, so the timed baseline is the C port (which is ~70x faster per core "
                         "than the reference because it has no Python call overhead -- a stronger baseline)"}}
 
 
@@ -223,7 +223,7 @@ def tolerance_probe(B, d, N, seed, sd2, status):
             "note": "NOT the product: measurement build answering 'what does bit-exactness cost' (the product replicates the "
                     "reference's last-pivot arithmetic FMA-free with correctly rounded divisions; this build returns the "
                     "certified vertex itself, with contracted multiply-adds and reciprocal division).  The north star's bar is "
-                    "1e-8 on sd^2; tools/gpu_tolerance_report.py checks every fixture (profiles/r02_tolerance_report.json)"}
+                    "1e-8 on sd^2; tools/gpu_tolerance_report.py checks every fixture (profiles/r03_tolerance_report.json)"}
 
 
 def baseline_configs(torch, tb, dev):
@@ -632,7 +632,7 @@ def main():
                 "traffic_source": (pmc["source"] + " -- REPLAYED from the committed profile, not measured in this run") if pmc else None,
                 "pmc": pmc,
                 "note": "the fused path is bound by fp64 VALU issue and, at one wave per SIMD, by its own dependency "
-                        "latencies -- not by HBM: DESIGN.md section 3.5; see roofline_compute",
+                        "latencies -- not by HBM: DESIGN.md section 3.8; see roofline_compute",
             },
             "roofline_compute": compute_roofline(pmc, kernel_ms),
         }

@@ -23,6 +23,19 @@ timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.log
 timeout 900 python tools/gpu_shortcut_stress.py ${STRESS_ROUNDS:-2} > gpurun_out/stress.log 2>&1; grep total gpurun_out/stress.log
 timeout 600 python tools/gpu_near_parallel.py > gpurun_out/near_parallel.log 2>&1; tail -1 gpurun_out/near_parallel.log
 timeout 600 python tools/gpu_tolerance_report.py 2>/dev/null > gpurun_out/tolerance_report.json; tail -5 gpurun_out/tolerance_report.json
+# round 3: the new kernels against their full-iteration / two-scan counterparts, the latency kernel's parity and timings
+timeout 600 python tools/gpu_feasible_check.py > gpurun_out/feasible_check.log 2>&1; tail -6 gpurun_out/feasible_check.log
+timeout 600 python tools/gpu_sd_check.py > gpurun_out/sd_check.log 2>&1; tail -8 gpurun_out/sd_check.log
+timeout 600 python tools/gpu_robust_check.py > gpurun_out/robust_check.log 2>&1; tail -6 gpurun_out/robust_check.log
+timeout 900 python tools/gpu_cert_dofs_check.py > gpurun_out/cert_dofs.log 2>&1; tail -9 gpurun_out/cert_dofs.log
+timeout 900 python tools/gpu_r3_stress.py ${STRESS_ROUNDS:-2} > gpurun_out/r3_stress.log 2>&1; tail -20 gpurun_out/r3_stress.log
+timeout 600 python tools/gpu_wave_check.py > gpurun_out/wave_check.log 2>&1; tail -12 gpurun_out/wave_check.log
+timeout 600 python tools/gpu_sliver_hunt.py > gpurun_out/sliver_hunt.log 2>&1; tail -3 gpurun_out/sliver_hunt.log
+timeout 300 python tools/gpu_mode_times.py > gpurun_out/mode_times.log 2>&1; cat gpurun_out/mode_times.log
+bash tools/gpu_profile_secondary.sh all > gpurun_out/sec_profile.log 2>&1; tail -3 gpurun_out/sec_profile.log
+if [ -f build_dbg/libtoppra_wtim.so ]; then
+  (TOPPRA_HIP_LIB=build_dbg/libtoppra_wtim.so timeout 120 python tools/gpu_wave_phases.py timing 4096 7 200; TOPPRA_HIP_LIB=build_dbg/libtoppra_wtim.so timeout 120 python tools/gpu_wave_phases.py timing 1 7 100) > gpurun_out/wave_phases.log 2>&1; tail -4 gpurun_out/wave_phases.log
+fi
 if [ -f build_dbg/libtoppra_tim.so ]; then
   TOPPRA_HIP_LIB=build_dbg/libtoppra_tim.so timeout 300 python tools/gpu_cert_phases.py > gpurun_out/phases.log 2>&1; tail -3 gpurun_out/phases.log
 fi

@@ -47,7 +47,7 @@ CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "12"))
 CERT_DOFS = tuple(range(1, CERT_MAX_DOF + 1))
 
 
-def _compile_and_link(target, flags, defines, verbose, single_tu):
+def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=None):
     """hipcc the translation units in parallel (the certified lane kernels are most of the compile time: one unit per
     dof), then link the objects into `target`.  Instrumented development builds (`defines`) are ONE translation unit:
     their counters are device globals, and they instantiate 7 dof only."""
@@ -64,8 +64,9 @@ def _compile_and_link(target, flags, defines, verbose, single_tu):
         subprocess.check_call(cmd, cwd=CSRC)
         return target
     with tempfile.TemporaryDirectory(prefix="tpr_build_") as tmp:
-        jobs = [(main, os.path.join(tmp, "main.o"), ["-DTPR_CERT_MAX_DOF=%d" % CERT_MAX_DOF])]
-        for d in CERT_DOFS:
+        max_dof = cert_max_dof or CERT_MAX_DOF
+        jobs = [(main, os.path.join(tmp, "main.o"), ["-DTPR_CERT_MAX_DOF=%d" % max_dof])]
+        for d in range(1, max_dof + 1):
             jobs.append((os.path.join(CSRC, "tpr_cert_tu.hip"), os.path.join(tmp, "cert%d.o" % d), ["-DTPR_TU_D=%d" % d]))
         for half in (0, 1):  # the robust (conic) kernels: 1..8 dof + the lane kernel, 9..16 dof
             jobs.append((os.path.join(CSRC, "tpr_robust_tu.hip"), os.path.join(tmp, "robust%d.o" % half), ["-DTPR_TU_HALF=%d" % half]))
@@ -95,7 +96,8 @@ def build_tolerance(out=None, verbose=False):
     product to ~1e-12, status codes identical; it is NOT the product library and nothing loads it by default."""
     target = os.path.abspath(out) if out else os.path.join(HERE, "libtoppra_hip_tol.so")
     flags = [f for f in FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast", "-freciprocal-math"]
-    return _compile_and_link(target, flags, ["TPR_TOLERANCE_MODE"], verbose, single_tu=False)
+    # (family 3 up to 8 dof is all the measurement needs: half of the product library's translation units)
+    return _compile_and_link(target, flags, ["TPR_TOLERANCE_MODE"], verbose, single_tu=False, cert_max_dof=min(CERT_MAX_DOF, 8))
 
 
 def build(force=False, verbose=False, defines=(), out=None):
