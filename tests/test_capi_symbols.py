@@ -67,3 +67,15 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".inc", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower().replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_integration_stub_declares_the_same_structs():
+    """The ctypes stub INTEGRATION.md hands to a toppra maintainer must declare tpr_problem / tpr_result field for field
+    as the package's own binding does (a struct that is one pointer short makes the library read past its end)."""
+    from toppra_amd import _capi
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name, cls in (("tpr_problem", _capi.tpr_problem), ("tpr_result", _capi.tpr_result)):
+        block = re.search(r"class %s\(C\.Structure\):\s*_fields_ = \[(.*?)\]\s*(#[^\n]*)?\n\n" % name, text, re.S)
+        assert block, name
+        fields = re.findall(r'\("(\w+)",\s*C\.(\w+)\)', block.group(1))
+        assert [(n, getattr(ctypes, t)) for n, t in fields] == [(n, t) for n, t in cls._fields_], name
