@@ -1044,7 +1044,11 @@ int tpr_const_accel_times_batch(const tpr_problem *p, const double *sd, double *
     A.ts = S.out(ts, B * (N + 1));
     A.us = S.out(us, B * N);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    if (A.B > 0) hipLaunchKernelGGL(tpr::const_accel_times_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A);
+    if (A.B > 0) {
+        const size_t lds = 2 * ((size_t)A.N + 1) * sizeof(double);
+        if (lds <= kMaxDynamicLds) hipLaunchKernelGGL(tpr::const_accel_times_kernel, dim3(A.B), dim3(64), lds, stream, A);
+        else hipLaunchKernelGGL(tpr::const_accel_times_lane_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A);
+    }
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
@@ -1205,6 +1209,8 @@ int tpr_ppoly_eval_batch(int B, int nseg, int d, const double *coef, const doubl
     A.out = S.out(out, (size_t)B * T * d);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     const long long total = (long long)B * T;
+    // (a block per path with the breakpoints searched in LDS was tried in round 3: 1.07 -> 1.20 ms at 65536 x 64 -- the
+    // four scattered coefficient rows per sample are what the kernel waits for, not the search)
     if (total > 0)
         hipLaunchKernelGGL(tpr::ppoly_eval_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, A);
     HIP_TRY(S.finish());
