@@ -1089,15 +1089,19 @@ int launch_spline_fit(const tpr::SplineArgs &A, const int32_t *counts, Staging &
     const long long total = (long long)A.B * A.d;
     if (total <= 0) return TPR_E_OK;
     const dim3 grid((unsigned)((total + 127) / 128)), block(128);
+    if (A.m <= 8) {  // the usual handful of waypoints: unrolled, arrays in registers
+        hipLaunchKernelGGL((tpr::spline_fit_kernel<8>), grid, block, 0, stream, A, counts, (double *)nullptr);
+        return TPR_E_OK;
+    }
     if (A.m <= tpr::kSplineMaxPts) {
-        hipLaunchKernelGGL((tpr::spline_fit_kernel<false>), grid, block, 0, stream, A, counts, (double *)nullptr);
+        hipLaunchKernelGGL((tpr::spline_fit_kernel<tpr::kSplineMaxPts>), grid, block, 0, stream, A, counts, (double *)nullptr);
         return TPR_E_OK;
     }
     void *ws = nullptr;
     hipError_t e = hipMallocAsync(&ws, (size_t)6 * A.m * (size_t)total * sizeof(double), stream);
     if (e != hipSuccess) return fail(TPR_E_HIP, std::string("spline-fit workspace: ") + hipGetErrorString(e));
     S.owned.push_back(ws);
-    hipLaunchKernelGGL((tpr::spline_fit_kernel<true>), grid, block, 0, stream, A, counts, static_cast<double *>(ws));
+    hipLaunchKernelGGL((tpr::spline_fit_kernel<0>), grid, block, 0, stream, A, counts, static_cast<double *>(ws));
     return TPR_E_OK;
 }
 }  // namespace
