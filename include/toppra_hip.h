@@ -143,8 +143,10 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream);
  * desired_duration_algorithm.py:42-234) for B trajectories: the backward scan, the "fastest" and
  * "slowest" forward scans, the duration bisection on their convex combination (absolute tolerance
  * atol, reference default 1e-5) and the blended sd^2 / u.  desired [B] seconds; alpha [B] (may be
- * NULL) receives the blend factor.  Same result struct and status codes as tpr_solve_batch.
- * Needs the rows-across-lanes kernels (acceleration constraint with Interpolation).                */
+ * NULL) receives the blend factor.  Same result struct and status codes as tpr_solve_batch; up to 16 dof.
+ * p->variant: 0 = auto -- from 14336 trajectories up to 8 dof (24576 at 9..12 dof) the certified lane kernel runs the
+ * backward scan and both forward profiles in ONE launch, the rows-across-lanes kernels otherwise; 2 / 3 force one.
+ * Bisection and blend: one wave per trajectory.                                                      */
 int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired, double atol,
                                      const tpr_result *r, double *alpha, void *stream);
 
@@ -156,17 +158,22 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
  * NULL) with the stage problems ecosWrapper.solve_stagewise_optim builds
  * (solverwrapper/ecos_solverwrapper.py:90-207, constraint/conic_constraint.py:19-26) solved exactly
  * instead of by ECOS's interior-point iteration.  ellipsoid = (ru, rx, rc) axes lengths.  The
- * acceleration discretisation follows p->flags (TPR_ACC_INTERPOLATION or Collocation).             */
+ * acceleration discretisation follows p->flags (TPR_ACC_INTERPOLATION or Collocation).  p->variant: 0 = auto (rows
+ * across lanes up to 16 dof -- Interpolation or Collocation, with or without X --, the generic one-trajectory-per-lane
+ * kernel above), 1 = the generic kernel; same bits.                                                   */
 int tpr_robust_solve_batch(const tpr_problem *p, const double *ellipsoid, const tpr_result *r, double *X,
                            void *stream);
 
 /* Replaces ReachabilityAlgorithm.compute_controllable_sets(sdmin, sdmax)
- * (reachability_algorithm.py:166-238).  sdmin/sdmax [B]; K [B][N+1][2].                          */
+ * (reachability_algorithm.py:166-238).  sdmin/sdmax [B]; K [B][N+1][2].  Kernel selection and flags as
+ * tpr_solve_batch (backward scan only).                                                           */
 int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const double *sdmax,
                                 double *K, void *stream);
 
 /* Replaces ReachabilityAlgorithm.compute_feasible_sets (reachability_algorithm.py:131-164).
- * X [B][N+1][2].                                                                                 */
+ * X [B][N+1][2].  p->variant: 0 = auto (one wave per trajectory for a handful of trajectories, above 16 dof or with
+ * p->active; the certified lane kernel from 8192 trajectories up to 8 dof, 24576 at 9..12 dof; rows across lanes
+ * otherwise), 1 / 2 / 3 / 4 force a kernel family.  TPR_STRICT_SEIDEL / TPR_SOUND_CERTIFICATES as tpr_solve_batch.   */
 int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream);
 
 /* Replaces ReachabilityAlgorithm.compute_reachable_sets(sdmin, sdmax) (reachability_algorithm.py:378-431):
