@@ -290,7 +290,7 @@ def baseline_configs(torch, tb, dev):
     res["C5_batch524288_8gpu"] = "this bench with --gpus 8 (65536 trajectories per rank + RCCL gather of sd^2)"
     res["large_batch262144_d7_N200"] = dict(kernel(262144, 7, 200, reps=3),
                                             note="four rounds of one wave per SIMD: the kernel has no two-waves-per-SIMD variant (DESIGN.md 3.8)")
-    res["d12_batch65536_N200"] = dict(kernel(65536, 12, 200, reps=3), note="kernel family 3 at 12 dof: three blocks per CU (DESIGN.md 3.2)")
+    res["d12_batch65536_N200"] = dict(kernel(65536, 12, 200, reps=3), note="kernel family 3 at 12 dof: slim blocks, four per CU (DESIGN.md 3.2)")
     # PCIe-inclusive: numpy in -> numpy out through the host-buffer entry (H2D 59 MB, kernel, D2H)
     datah = tb.make_synthetic_batch(65536, 7, 200)
     hargs = [datah[k] for k in ("coef", "breaks", "grid", "vlim", "alim")]

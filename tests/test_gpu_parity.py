@@ -157,9 +157,9 @@ def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
     assert X.shape == (64, N + 1, 2) and not np.isnan(X).any()
 
 
-@pytest.mark.parametrize("d", [9, 10, 11, 12])
+@pytest.mark.parametrize("d", [9, 10, 11, 12, 13])
 def test_certified_lane_kernel_above_8_dof(gpu, d):
-    """Round 3: family 3 serves 9..12 dof too (internal row numbering with a block stride of 16): solve (fast
+    """Round 3: family 3 serves 9..13 dof too (internal row numbering with a block stride of 16): solve (fast
     certificates; scaled paths, boundary velocities, Collocation), feasible sets and TOPPRAsd against the rows-across-lanes
     kernels -- the full iteration where there is a strict mode -- bit for bit."""
     B, N = 1200, 50

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Family 3 (the certified lane kernels) above 8 dof: solve, feasible sets and TOPPRAsd for d = 9..12 against the
+"""Family 3 (the certified lane kernels) above 8 dof: solve, feasible sets and TOPPRAsd for d = 9..13 against the
 rows-across-lanes kernels (full iteration where there is a strict mode) bit for bit, and timings at 65536 x d x 200.
 
   python tools/gpu_cert_dofs_check.py [--quick]
@@ -38,7 +38,7 @@ def check(label, got, want, keys):
 
 def main():
     quick = "--quick" in sys.argv
-    dofs = (9, 12) if quick else range(9, 13)   # (family 3 is instantiated up to 12 dof)
+    dofs = (9, 13) if quick else range(9, 14)   # (family 3 is instantiated up to 13 dof)
     for d in dofs:
         B, N = 1500, 60
         data = tb.make_synthetic_batch(B, d, N, seed=800 + d)
@@ -65,7 +65,7 @@ def main():
                 got = tb.solve_desired_duration_batch(*args, desired, variant=3, **kw)
                 check("d%d %-11s TOPPRAsd v3 vs v2" % (d, name), got, want, ("K", "sd2", "sd", "u", "status", "alpha"))
     dev = torch.device("cuda", 0)
-    for d in ((9, 12) if quick else (8, 9, 10, 11, 12)):
+    for d in ((9, 13) if quick else (8, 9, 10, 11, 12, 13)):
         data = tb.make_synthetic_batch(65536, d, 200)
         dv = [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]
         out = tb.solve_batch(*dv, variant=2)

@@ -40,10 +40,11 @@ def stale():
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in deps())
 
 
-# kernel family 3: one translation unit per dof (csrc/tpr_cert_tu.hip), 1..12: above that its per-lane state no longer fits the
-# register file (620 B of scratch at 14 dof) and the rows-across-lanes kernels are faster (65536 x 14 x 200: 9.3 vs 8.6 ms).
+# kernel family 3: one translation unit per dof (csrc/tpr_cert_tu.hip), 1..13: above that a block no longer fits a quarter of a
+# CU's LDS (four blocks per CU = one wave per SIMD = a 65536-trajectory batch in one round) and the rows-across-lanes kernels
+# are faster (65536 x 14 x 200: 9.3 vs 8.6 ms).
 # TPR_BUILD_CERT_MAX_DOF=8 for quicker development builds
-CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "12"))
+CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "13"))
 CERT_DOFS = tuple(range(1, CERT_MAX_DOF + 1))
 
 

@@ -37,8 +37,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_laun
     // the shared grid goes to LDS only while four blocks still fit a CU (160 KB): a fifth of the
     // 1024 blocks of a 65536-trajectory batch would otherwise wait for a second round
     const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
-    const size_t static_lds = (((6 * D + 6) > 24 ? (6 * D + 6) : 24) * BS + tpr::kCertXch * BS +
-                               tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
+    using CS = tpr::CertStage<D, BS>;
+    const size_t static_lds = (((4 * D + CS::kLimCols) > 24 ? (4 * D + CS::kLimCols) : 24) * BS + tpr::kCertXch * BS +
+                               tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + CS::kRing * 2 * BS) * sizeof(double);
     // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
     // wave per SIMD --, three at 9..11 dof, two above)
     // ... and only up to 8 dof: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
@@ -70,8 +71,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feas
     const tpr::GroupArgs &G = *Gp;
     const dim3 grid((G.B + BS - 1) / BS), block(BS);
     const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
-    const size_t static_lds = (((6 * D + 6) > 24 ? (6 * D + 6) : 24) * BS + tpr::kCertXch * BS +
-                               tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
+    using CS = tpr::CertStage<D, BS>;
+    const size_t static_lds = (((4 * D + CS::kLimCols) > 24 ? (4 * D + CS::kLimCols) : 24) * BS + tpr::kCertXch * BS +
+                               tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + CS::kRing * 2 * BS) * sizeof(double);
     // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
     // wave per SIMD --, three at 9..11 dof, two above)
     // ... and only up to 8 dof: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
@@ -97,8 +99,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_l
     const tpr::GroupArgs &G = *Gp;
     const dim3 grid((G.B + BS - 1) / BS), block(BS);
     const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
-    const size_t cols = ((6 * D + 6) > 32 ? (6 * D + 6) : 32) * BS;
-    const size_t static_lds = (cols + tpr::kCertXch * BS + tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 8 * BS) * sizeof(double);
+    using CS = tpr::CertStage<D, BS>;
+    const size_t cols = ((4 * D + CS::kLimCols) > 32 ? (4 * D + CS::kLimCols) : 32) * BS;
+    const size_t static_lds = (cols + tpr::kCertXch * BS + tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + CS::kRing * 2 * BS) * sizeof(double);
     // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
     // wave per SIMD --, three at 9..11 dof, two above)
     // ... and only up to 8 dof: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
