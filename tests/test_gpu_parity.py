@@ -187,3 +187,24 @@ def test_certified_lane_kernel_above_8_dof(gpu, d):
         got = batch.solve_desired_duration_batch(*args[:5], desired, sd0, sd1, variant=3, interpolation=interp)
         for k in ("K", "sd2", "u", "status", "alpha"):
             assert np.array_equal(got[k], want[k], equal_nan=True), (k, interp)
+
+
+@pytest.mark.parametrize("B,d,N", [(1, 9, 7), (65, 13, 5), (3, 12, 2), (130, 10, 1)])
+def test_slim_blocks_partial_and_tiny(gpu, B, d, N):
+    """The slim blocks of family 3 above 8 dof read another lane's acceleration limits from global memory in the
+    cooperative batches and flush K two stages at a time: partial blocks (idle lanes shadow the last trajectory), odd and
+    tiny stage counts."""
+    data = batch.make_synthetic_batch(B, d, N, seed=7 * d + N)
+    rng = np.random.default_rng(B)
+    sd1 = np.where(rng.random(B) < 0.5, 0.2 * rng.random(B), 0.0)
+    scale = 10.0 ** rng.uniform(-4, 0, size=(B, 1, 1, 1))
+    for interp in (True, False):
+        args = (data["coef"] * scale, data["breaks"], data["grid"], data["vlim"], data["alim"], None, sd1, interp)
+        full = batch.solve_batch(*args, variant=2, strict=True)
+        got = batch.solve_batch(*args, variant=3)
+        for k in ("K", "sd2", "u", "status"):
+            assert np.array_equal(got[k], full[k], equal_nan=True), (k, interp)
+        fargs = args[:5] + (interp,)
+        assert np.array_equal(batch.feasible_sets_batch(*fargs, variant=3), batch.feasible_sets_batch(*fargs, variant=2, strict=True), equal_nan=True)
+        K = batch.controllable_sets_batch(*args[:5], 0.0, sd1, interp, variant=3)
+        assert np.array_equal(K, batch.controllable_sets_batch(*args[:5], 0.0, sd1, interp, variant=2, strict=True), equal_nan=True)
