@@ -699,6 +699,16 @@ int tpr_init(int device) {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(TPR_E_UNSUPPORTED, std::string("this library is built for gfx950 only, found ") + prop.gcnArchName);
+        // Workspaces and host-call staging come from the device's stream-ordered pool (hipMallocAsync).  Its default
+        // release threshold is 0: whatever was freed goes back to the driver at the next synchronisation, and a call that
+        // needs a 1.2 GB workspace (tpr_param_spline_batch at the headline shape) maps it afresh every time -- 65 ms per
+        // call instead of 2 on some boxes (profiles/r03: the kernel itself takes 1.9 ms).  Keep freed memory in the pool.
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+            uint64_t keep = UINT64_MAX;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
         g_checked[device].store(true, std::memory_order_release);
     }
     t_device = device;  // the caller's current device is left alone: every entry scopes its own (DeviceScope)
