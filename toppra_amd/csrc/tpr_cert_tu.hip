@@ -17,12 +17,15 @@
 #error "compile with -DTPR_TU_D=<dof 1..8>"
 #endif
 
-// The sound certificate mode is instantiated up to 8 dof only: at 9..12 dof the sound instantiations returned lower bounds
-// that were off in the last bits on up to 0.9 % of an irregular batch (asymmetric limits, standing joints, non-uniform
-// grids: tools/gpu_r3_stress.py) -- only they, deterministically, and not once the source was perturbed by a debug store
-// or the grid read from global memory; the fast instantiations of the same dofs are bit-exact on 0.8 M trajectories of
-// both stress families.  Not understood; sound requests above 8 dof are served by the
-// rows-across-lanes kernels, whose sound mode is bit-exact there.  -2 = not instantiated.
+// The sound certificate mode is instantiated up to 8 dof only.  Above that the kernels sit at the limit of the register file
+// (512 registers, ~100 scalar registers spilled into vector lanes, ~150 vector registers spilled to scratch) and some
+// SOUND instantiations are miscompiled by this toolchain (ROCm 7.2 hipcc): 9 dof with the pre-slim layout returned lower
+// bounds off in the last bits on 0.9 % of an irregular batch; with the slim layout cert_feasible_kernel<11 | 13,
+// Interpolation, sound> runs 7 x longer than it should and stores nothing at all -- one trajectory, two stages reproduce
+// it -- while either of two unrelated source perturbations (fast proposal + sound batches, or the reverse) makes the same
+// instantiation bit-exact, as are the neighbouring dofs, Collocation, and every fast instantiation (DESIGN.md section
+// 3.2).  Sound requests above 8 dof are served by the rows-across-lanes kernels, whose sound mode is bit-exact there.
+// -2 = not instantiated.
 constexpr bool kSoundHere = TPR_TU_D <= 8;
 
 #define TPR_TU_CAT2(a, b) a##b

@@ -194,7 +194,10 @@ struct Staging {
     }
     hipError_t finish() {
         if (err != hipSuccess) return err;
-        if (device_ptrs) return hipGetLastError();
+        // a kernel that could not be launched leaves its error in the runtime's per-thread slot only: ask for it on
+        // both paths (round 3: a host-buffer call whose launch failed returned uninitialised outputs without a word)
+        const hipError_t launch = hipGetLastError();
+        if (launch != hipSuccess || device_ptrs) return launch;
         for (auto &o : outs) {
             err = hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream);
             if (err != hipSuccess) return err;
