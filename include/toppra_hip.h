@@ -247,7 +247,11 @@ int tpr_const_accel_eval_batch(const tpr_problem *p, const double *sd, const dou
  * waypoints q(s_i) and the cubic spline in time through them, clamped to q'(s) sd at both ends (scipy
  * CubicSpline arithmetic as in tpr_spline_fit_batch).  sd [B][N+1] -> knot_times [B][N+1] (compacted;
  * entries from counts[b] on are padding), counts [B] (gridpoints kept), coef_t [B][4][N][d] (segments from
- * counts[b]-1 on are a constant extension).  Uses p->coef/breaks/grid/flags.
+ * counts[b]-1 on are a constant extension).  Uses p->coef/breaks/grid/flags and p->variant: 0 = auto, 1 = generic (two
+ * kernels, any d), 2 = one fused kernel in LAPACK dgtsv's elimination order (d <= 64; the bits of scipy on an FMA-free
+ * LAPACK), 3 = knot-parallel (d <= 8, all knots in LDS; cyclic reduction instead of dgtsv: the knot derivatives agree to
+ * rounding, q(t) within 1e-10 of the reference's samples like variant 2; twice as fast).  Auto picks 3 where it fits,
+ * else 2, else 1.  Time stamps, counts and waypoints are the same bits in every variant.
  * tpr_ppoly_eval_batch evaluates such tables -- SplineInterpolator.__call__(t, order), i.e. scipy PPoly
  * (interpolator.py:423-430) -- at times [B][T] -> out [B][T][d]; breaks [B][nseg+1]; counts may be NULL.   */
 int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_times, int32_t *counts,

@@ -1164,6 +1164,33 @@ int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_
     K.counts = S.out(counts, B);
     double *dcoef = S.out(coef_t, B * 4 * N * d);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (p->variant < 0 || p->variant > 3) return fail(TPR_E_BADARG, "spline parametrizer: variant 0 (auto), 1 (generic), 2 (fused, LAPACK order), 3 (knot-parallel)");
+    // knot-parallel kernel (tpr_spline.hip.inc): a block per trajectory, all N + 1 knots with their d right-hand sides in LDS
+    const size_t pcr_lds = (2 * (N + 1) + (d + std::max<size_t>(d, 2)) * ((N + 1) | 1)) * sizeof(double);
+    const bool pcr_fits = d <= 8 && N + 1 <= 1024 && pcr_lds <= kMaxDynamicLds - 64;
+    if (p->variant == 3 && !pcr_fits)
+        return fail(TPR_E_UNSUPPORTED, "spline parametrizer variant 3 needs d <= 8 and about 2 (d + 1) (N + 1) doubles of LDS (<= 64 KB)");
+    if (B > 0 && pcr_fits && (p->variant == 0 || p->variant == 3)) {
+        const int kpt = N + 1 <= 256 ? 1 : (N + 1 <= 512 ? 2 : 4);
+        int pcr_debug = 0;
+#if TPR_PS_EXPERIMENT
+        if (const char *e = getenv("TPR_PS_DEBUG")) pcr_debug = atoi(e);
+#endif
+        const dim3 grid((unsigned)B), block(256);
+#define TPR_PCR_CASE(DD) \
+        case DD: \
+            if (kpt == 1) hipLaunchKernelGGL((tpr::param_spline_pcr_kernel<DD, 1>), grid, block, pcr_lds, stream, K, dcoef, pcr_debug); \
+            else if (kpt == 2) hipLaunchKernelGGL((tpr::param_spline_pcr_kernel<DD, 2>), grid, block, pcr_lds, stream, K, dcoef, pcr_debug); \
+            else hipLaunchKernelGGL((tpr::param_spline_pcr_kernel<DD, 4>), grid, block, pcr_lds, stream, K, dcoef, pcr_debug); \
+            break
+        switch (p->d) {
+            TPR_PCR_CASE(1); TPR_PCR_CASE(2); TPR_PCR_CASE(3); TPR_PCR_CASE(4);
+            TPR_PCR_CASE(5); TPR_PCR_CASE(6); TPR_PCR_CASE(7); TPR_PCR_CASE(8);
+        }
+#undef TPR_PCR_CASE
+        HIP_TRY(S.finish());
+        return TPR_E_OK;
+    }
     if (B > 0 && d <= 64 && N <= 65535 && p->variant != 1) {
         // one kernel (tpr_spline.hip.inc): a wave owns floor(64/d) trajectories; workspace = the eliminated right-hand
         // sides [tasks][N+1][64], the eliminated matrix rows [tasks][N+1][3][tpw], the knots' path positions [B][N+1]
