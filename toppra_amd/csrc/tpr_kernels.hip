@@ -1252,11 +1252,12 @@ int tpr_ppoly_eval_batch(int B, int nseg, int d, const double *coef, const doubl
     A.times = S.in(times, (size_t)B * T);
     A.out = S.out(out, (size_t)B * T * d);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    const long long total = (long long)B * T;
-    // (a block per path with the breakpoints searched in LDS was tried in round 3: 1.07 -> 1.20 ms at 65536 x 64 -- the
-    // four scattered coefficient rows per sample are what the kernel waits for, not the search)
+    const long long total = (long long)B * T * d;  // one thread per (sample, dof)
+    if (total > (long long)0x7fffffff * 256) return fail(TPR_E_BADARG, "piecewise-polynomial evaluation: B T d too large for one launch");
+    // (round 3 also tried a block per path with the breakpoints searched in LDS on the thread-per-sample form: 1.07 ->
+    // 1.20 ms -- the scattered coefficient rows were what it waited for, not the search)
     if (total > 0)
-        hipLaunchKernelGGL(tpr::ppoly_eval_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, A);
+        hipLaunchKernelGGL(tpr::ppoly_eval_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, A);
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
