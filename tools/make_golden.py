@@ -424,6 +424,15 @@ def pow_fixture(name="pow_boundary_d3_N40", B=16, d=3, N=40, seed=61):
           int((out["K"][:, N, 0] != out["sd_end"] * out["sd_end"]).sum()))
 
 
+def high_dof_fixtures():
+    """round 3: the slim blocks of kernel family 3 (9..13 dof: 11 with boundary velocities, 13 with Collocation) and the
+    two / three row slots per lane of family 4 above 16 dof (24, 32 dof)"""
+    batch_fixture("batch_d11_N50_boundary", 8, 11, 50, seed=16, sd_mode="random", feasible=True)
+    batch_fixture("batch_d13_N40_collocation", 6, 13, 40, seed=17, scheme=0, feasible=True)
+    batch_fixture("batch_d24_N30", 4, 24, 30, seed=18)
+    batch_fixture("batch_d32_N20_boundary", 3, 32, 20, seed=19, sd_mode="random")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if "--reuse-only" in sys.argv:
@@ -433,6 +442,9 @@ if __name__ == "__main__":
     if "--reachable-only" in sys.argv:
         reachable_fixture()
         reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)
+        raise SystemExit(0)
+    if "--high-dof-only" in sys.argv:
+        high_dof_fixtures()
         raise SystemExit(0)
     example_fixture()
     cpp_fixture()
@@ -453,6 +465,7 @@ if __name__ == "__main__":
     batch_fixture("batch_d9_N60", 8, 9, 60, seed=13, feasible=True)
     batch_fixture("batch_d14_N40_boundary", 6, 14, 40, seed=14, sd_mode="random")
     batch_fixture("batch_d16_N30", 4, 16, 30, seed=15)
+    high_dof_fixtures()
     reachable_fixture()
     reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)
     reuse_fixture()

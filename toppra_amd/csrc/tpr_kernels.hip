@@ -1088,9 +1088,10 @@ int tpr_const_accel_eval_batch(const tpr_problem *p, const double *sd, const dou
     A.times = S.in(times, B * (size_t)T);
     A.out = S.out(out, B * (size_t)T * d);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    const long long total = (long long)p->B * T;
+    const long long total = (long long)p->B * T * p->d;  // one thread per (sample, dof)
+    if (total > (long long)0x7fffffff * 256) return fail(TPR_E_BADARG, "constant-acceleration evaluation: B T d too large for one launch");
     if (total > 0)
-        hipLaunchKernelGGL(tpr::const_accel_eval_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, A);
+        hipLaunchKernelGGL(tpr::const_accel_eval_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, A);
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
