@@ -249,7 +249,7 @@ int tpr_const_accel_eval_batch(const tpr_problem *p, const double *sd, const dou
  * entries from counts[b] on are padding), counts [B] (gridpoints kept), coef_t [B][4][N][d] (segments from
  * counts[b]-1 on are a constant extension).  Uses p->coef/breaks/grid/flags and p->variant: 0 = auto, 1 = generic (two
  * kernels, any d), 2 = one fused kernel in LAPACK dgtsv's elimination order (d <= 64; the bits of scipy on an FMA-free
- * LAPACK), 3 = knot-parallel (d <= 8, all knots in LDS; cyclic reduction instead of dgtsv: the knot derivatives agree to
+ * LAPACK), 3 = knot-parallel (d <= 16, all knots in LDS; cyclic reduction instead of dgtsv: the knot derivatives agree to
  * rounding, q(t) within 1e-10 of the reference's samples like variant 2; twice as fast).  Auto picks 3 where it fits,
  * else 2, else 1.  Time stamps, counts and waypoints are the same bits in every variant.
  * tpr_ppoly_eval_batch evaluates such tables -- SplineInterpolator.__call__(t, order), i.e. scipy PPoly

@@ -156,9 +156,9 @@ def _spline_deviation(a, b):
 
 
 @pytest.mark.parametrize("B,d,N", [(300, 7, 200), (70, 1, 64), (64, 8, 255), (33, 2, 256), (40, 6, 500), (20, 3, 1000),
-                                   (100, 5, 3), (50, 5, 1), (17, 4, 2)])
+                                   (100, 5, 3), (50, 5, 1), (17, 4, 2), (40, 12, 150), (24, 16, 100)])
 def test_param_spline_knot_parallel_kernel(gpu, B, d, N):
-    """The knot-parallel ParametrizeSpline kernel (variant 3, the default up to 8 dof: a block per trajectory, cyclic
+    """The knot-parallel ParametrizeSpline kernel (variant 3, the default up to 16 dof: a block per trajectory, cyclic
     reduction instead of LAPACK's elimination) against the LAPACK-order kernel (variant 2).  Bit for bit: knot times,
     counts (ragged knot vectors, single knots, NaN profiles: the harsh profiles of the test above).  To rounding: the
     knot derivatives and hence the table -- on solved velocity profiles q(t) agrees to 1e-13 of the trajectory's range,
@@ -195,7 +195,7 @@ def test_param_spline_knot_parallel_kernel(gpu, B, d, N):
         else:
             assert dev[1][1] <= 1e-10 and dev[2][1] <= 1e-10, dev
     with pytest.raises(Exception):
-        batch.param_spline_batch(np.zeros((1, 4, 2, 9)), np.array([0.0, 0.5, 1.0]), np.linspace(0, 1, 5), np.ones((1, 5)), variant=3)
+        batch.param_spline_batch(np.zeros((1, 4, 2, 17)), np.array([0.0, 0.5, 1.0]), np.linspace(0, 1, 5), np.ones((1, 5)), variant=3)
 
 
 @pytest.mark.parametrize("kind", ["ParametrizeSpline", "ParametrizeConstAccel"])

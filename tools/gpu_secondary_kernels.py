@@ -73,11 +73,13 @@ def main():
     cases["spline_fit_65536x7x5pts"] = lambda: tb.spline_fit_batch(knots, way)
     sol = tb.solve_batch(*dv, want_sd=True, want_K=False, want_u=False)
     cases["param_spline_65536x7x200"] = lambda: tb.param_spline_batch(dv[0], dv[1], dv[2], sol["sd"])
+    cases["param_spline_lapack_order_65536x7x200"] = lambda: tb.param_spline_batch(dv[0], dv[1], dv[2], sol["sd"], variant=2)
     sp = tb.param_spline_batch(dv[0], dv[1], dv[2], sol["sd"])
     times = torch.rand(B, 64, dtype=torch.float64, device=dev) * 2.0
     cases["ppoly_eval_65536x64"] = lambda: tb.ppoly_eval_batch(sp["coef"], sp["knot_times"], times, 0, sp["counts"])
     ts_us = tb.const_accel_times_batch(dv[2], sol["sd"])
     cases["const_accel_times_65536x200"] = lambda: tb.const_accel_times_batch(dv[2], sol["sd"])
+    cases["const_accel_eval_65536x64"] = lambda: tb.const_accel_eval_batch(dv[0], dv[1], dv[2], sol["sd"], ts_us[0], ts_us[1], times, 0)
     for name, fn in cases.items():
         if ONLY and ONLY not in name:
             continue

@@ -268,7 +268,7 @@ def param_spline_batch(coef, breaks, grid, sd, variant=0):
     time through q(s_i) at the gridpoint times, clamped to q'(s) sd at both ends.  Entries of
     ``knot_times`` from ``counts[b]`` on are padding (gridpoints reached in no time are dropped, as in the
     reference).  Evaluate with :func:`ppoly_eval_batch`.  ``variant``: 0 auto; 1 the generic two-kernel path (any d);
-    2 the single fused kernel in LAPACK dgtsv's elimination order (same bits as 1); 3 the knot-parallel kernel (d <= 8,
+    2 the single fused kernel in LAPACK dgtsv's elimination order (same bits as 1); 3 the knot-parallel kernel (d <= 16,
     knots in LDS, cyclic reduction: knot derivatives equal to rounding, q(t) within the row's 1e-10; the default where it
     fits).  Knot times and counts are the same bits in every variant."""
     _prepare(coef)

@@ -1168,9 +1168,9 @@ int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_
     if (p->variant < 0 || p->variant > 3) return fail(TPR_E_BADARG, "spline parametrizer: variant 0 (auto), 1 (generic), 2 (fused, LAPACK order), 3 (knot-parallel)");
     // knot-parallel kernel (tpr_spline.hip.inc): a block per trajectory, all N + 1 knots with their d right-hand sides in LDS
     const size_t pcr_lds = (2 * (N + 1) + (d + std::max<size_t>(d, 2)) * ((N + 1) | 1)) * sizeof(double);
-    const bool pcr_fits = d <= 8 && N + 1 <= 1024 && pcr_lds <= kMaxDynamicLds - 64;
+    const bool pcr_fits = d <= 16 && N + 1 <= 1024 && pcr_lds <= kMaxDynamicLds - 256;
     if (p->variant == 3 && !pcr_fits)
-        return fail(TPR_E_UNSUPPORTED, "spline parametrizer variant 3 needs d <= 8 and about 2 (d + 1) (N + 1) doubles of LDS (<= 64 KB)");
+        return fail(TPR_E_UNSUPPORTED, "spline parametrizer variant 3 needs d <= 16 and about 2 (d + 1) (N + 1) doubles of LDS (<= 64 KB)");
     if (B > 0 && pcr_fits && (p->variant == 0 || p->variant == 3)) {
         const int kpt = N + 1 <= 256 ? 1 : (N + 1 <= 512 ? 2 : 4);
         int pcr_debug = 0;
@@ -1187,6 +1187,8 @@ int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_
         switch (p->d) {
             TPR_PCR_CASE(1); TPR_PCR_CASE(2); TPR_PCR_CASE(3); TPR_PCR_CASE(4);
             TPR_PCR_CASE(5); TPR_PCR_CASE(6); TPR_PCR_CASE(7); TPR_PCR_CASE(8);
+            TPR_PCR_CASE(9); TPR_PCR_CASE(10); TPR_PCR_CASE(11); TPR_PCR_CASE(12);
+            TPR_PCR_CASE(13); TPR_PCR_CASE(14); TPR_PCR_CASE(15); TPR_PCR_CASE(16);
         }
 #undef TPR_PCR_CASE
         HIP_TRY(S.finish());
