@@ -163,8 +163,8 @@ def test_param_spline_knot_parallel_kernel(gpu, B, d, N):
     counts (ragged knot vectors, single knots, NaN profiles: the harsh profiles of the test above).  To rounding: the
     knot derivatives and hence the table -- on solved velocity profiles q(t) agrees to 1e-13 of the trajectory's range,
     dq/dt to 1e-12, d2q/dt2 to 1e-10 (measured: 4e-16, 2e-15, 1e-12; the row's bar against the reference is 1e-10).  On
-    the harsh profiles (time steps of 1e-8 s next to 5 s: knot derivatives of 1e12) only relative statements make
-    sense: derivatives agree to 1e-10 of their range."""
+    the harsh profiles (time steps of 1e-8 s next to 5 s: knot derivatives of 1e12, splines that overshoot to 1e11)
+    only relative statements make sense: 1e-10 of each quantity's range (measured: 8e-14)."""
     rng = np.random.default_rng(1000 * d + N)
     data = batch.make_synthetic_batch(B, d, N, seed=5 + d)
     solved = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], want_sd=True)["sd"]
@@ -193,7 +193,7 @@ def test_param_spline_knot_parallel_kernel(gpu, B, d, N):
         if kind == "solved":
             assert dev[0][1] <= 1e-13 and dev[1][1] <= 1e-12 and dev[2][1] <= 1e-10, dev
         else:
-            assert dev[1][1] <= 1e-10 and dev[2][1] <= 1e-10, dev
+            assert dev[0][1] <= 1e-10 and dev[1][1] <= 1e-10 and dev[2][1] <= 1e-10, dev
     with pytest.raises(Exception):
         batch.param_spline_batch(np.zeros((1, 4, 2, 17)), np.array([0.0, 0.5, 1.0]), np.linspace(0, 1, 5), np.ones((1, 5)), variant=3)
 

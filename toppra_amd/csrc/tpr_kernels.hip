@@ -1167,7 +1167,7 @@ int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
     if (p->variant < 0 || p->variant > 3) return fail(TPR_E_BADARG, "spline parametrizer: variant 0 (auto), 1 (generic), 2 (fused, LAPACK order), 3 (knot-parallel)");
     // knot-parallel kernel (tpr_spline.hip.inc): a block per trajectory, all N + 1 knots with their d right-hand sides in LDS
-    const size_t pcr_lds = (2 * (N + 1) + (d + std::max<size_t>(d, 2)) * ((N + 1) | 1)) * sizeof(double);
+    const size_t pcr_lds = (1 + d + std::max<size_t>(d - 1, 2)) * ((N + 1) | 1) * sizeof(double);
     const bool pcr_fits = d <= 16 && N + 1 <= 1024 && pcr_lds <= kMaxDynamicLds - 256;
     if (p->variant == 3 && !pcr_fits)
         return fail(TPR_E_UNSUPPORTED, "spline parametrizer variant 3 needs d <= 16 and about 2 (d + 1) (N + 1) doubles of LDS (<= 64 KB)");
