@@ -352,7 +352,7 @@ def end_to_end(torch, tb, dev, B=65536, d=7, N=200, samples=64):
             ("spline_fit", fit, 8 * (B * 5 * d + B * 4 * nseg * d)),
             ("solve_sd_only", solve, B * (8 * (4 * nseg * d + 4 * d) + 8 * 2 * (N + 1) + 4)),
             ("param_spline", param, 8 * B * ((N + 1) + 4 * nseg * d + 4 * N * d + (N + 1)) + 4 * B),
-            ("ppoly_eval_%d_samples" % samples, evaluate, 8 * B * (samples + samples * d) + 8 * B * 4 * N * d)):
+            ("ppoly_eval_%d_samples" % samples, evaluate, 8 * B * samples * (1 + d + 4 * d) + 8 * B * (N + 1))):
         ms = timed(fn)
         stages[name] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / (ms * 1e-3) / 1e9}
     total = sum(s["ms"] for s in stages.values())
@@ -361,8 +361,9 @@ def end_to_end(torch, tb, dev, B=65536, d=7, N=200, samples=64):
     return {"workload": "batch=%d, %d-DoF, 5 waypoints -> N=%d gridpoints -> %d samples of q(t) per trajectory; device-resident" % (B, d, N, samples),
             "stages": stages, "total_ms": total, "trajectories_per_s": B / total * 1e3, "ok_fraction": ok, "q_finite_where_ok": finite,
             "note": "param_spline writes the [B, 4, N, d] coefficient table (%.2f GB): the one HBM-bound stage of the pipeline "
-                    "(6.3 TB/s achievable: MI355X_MICROARCH.md); ppoly_eval's bytes count the whole table although %d samples touch "
-                    "at most %d of its N segments" % (8 * B * 4 * N * d / 1e9, samples, samples)}
+                    "(6.3 TB/s achievable: MI355X_MICROARCH.md); ppoly_eval's bytes are what its samples need (a time, four coefficient "
+                    "rows of d doubles and d outputs per sample, the breakpoints once): %d samples read a fraction of the table, at "
+                    "cache-line granularity" % (8 * B * 4 * N * d / 1e9, samples)}
 
 
 def main():
