@@ -354,7 +354,9 @@ def end_to_end(torch, tb, dev, B=65536, d=7, N=200, samples=64):
             ("param_spline", param, 8 * B * ((N + 1) + 4 * nseg * d + 4 * N * d + (N + 1)) + 4 * B),
             ("ppoly_eval_%d_samples" % samples, evaluate, 8 * B * samples * (1 + d + 4 * d) + 8 * B * (N + 1))):
         ms = timed(fn)
-        stages[name] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / (ms * 1e-3) / 1e9}
+        gbps = nbytes / (ms * 1e-3) / 1e9
+        stages[name] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": gbps, "hbm_frac_of_8TBps_peak": gbps / 8000.0,
+                        "hbm_frac_of_6.3TBps_achievable": gbps / 6300.0}
     total = sum(s["ms"] for s in stages.values())
     ok = float((state["sol"]["status"] == 0).double().mean().item())
     finite = bool(torch.isfinite(state["q"][state["sol"]["status"] == 0]).all().item())
