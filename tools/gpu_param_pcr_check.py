@@ -66,7 +66,7 @@ def deviation(a, b):
 
 def main():
     bad = 0
-    for B, d, N in ((300, 7, 200), (70, 1, 64), (64, 8, 255), (33, 2, 256), (40, 6, 500), (20, 3, 1000), (100, 5, 3), (50, 5, 1), (17, 4, 2), (40, 12, 150), (24, 16, 100)):
+    for B, d, N in ((4096, 7, 200), (300, 7, 200), (70, 1, 64), (64, 8, 255), (33, 2, 256), (40, 6, 500), (20, 3, 1000), (100, 5, 3), (50, 5, 1), (17, 4, 2), (40, 12, 150), (24, 16, 100)):
         rng = np.random.default_rng(1000 * d + N)
         data = tb.make_synthetic_batch(B, d, N, seed=5 + d)
         for kind in ("solved", "harsh"):
