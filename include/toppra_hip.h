@@ -184,6 +184,33 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream);
 int tpr_reachable_sets_batch(const tpr_problem *p, const double *sdmin, const double *sdmax, double *L, double *X,
                              void *stream);
 
+/* ---- the seidel path on DENSE rows: any canonical-linear constraint list ------------------------------
+ * The entries above regenerate the rows of JointVelocityConstraint + JointAccelerationConstraint from the spline table.
+ * seidelWrapper itself is more general (cy_seidel_solverwrapper.pyx:425-531): it flattens ANY list of canonical-linear
+ * constraints (SecondOrderConstraint / JointTorqueConstraint with a user's inverse dynamics, varying velocity limits,
+ * hand-written a, b, c, F, g) into a_arr, b_arr, c_arr [N+1][nC] (nC counts the two reserved x_next rows 0, 1),
+ * low_arr, high_arr [N+1][2] and deltas [N]; solve_stagewise_optim (:549-697) and the scans of
+ * reachability_algorithm.py:131-376 read nothing else.  These entries take exactly those arrays for B trajectories
+ * (the host side builds them as the reference does: toppra_amd.solverwrapper.dense_rows) and run every stage LP through
+ * the reference's full Seidel iteration with its warm-start state (rows across 8 / 16 lanes per trajectory; nC <= 66).
+ * Results are the reference's bits.  flags: TPR_DEVICE_PTRS, TPR_BOUNDARY_SQUARED.                          */
+typedef struct tpr_dense_problem {
+    int32_t B, N, nC, flags;
+    const double *a, *b, *c;         /* [B][N+1][nC]; entries 0, 1 of a stage are ignored (the x_next rows) */
+    const double *low, *high;        /* [B][N+1][2]  variable boxes (u, x) */
+    const double *deltas;            /* [B][N] */
+    const double *sd_start, *sd_end; /* [B] or NULL (zeros) */
+} tpr_dense_problem;
+
+/* compute_parameterization (reachability_algorithm.py:240-376): outputs and status codes as tpr_solve_batch (r->K is
+ * required; sd2 / sd / u / status may be NULL).                                                            */
+int tpr_solve_dense_batch(const tpr_dense_problem *p, const tpr_result *r, void *stream);
+/* compute_controllable_sets(sdmin, sdmax) (:166-238): K [B][N+1][2]; p->sd_start / sd_end are not used.       */
+int tpr_controllable_sets_dense_batch(const tpr_dense_problem *p, const double *sdmin, const double *sdmax, double *K,
+                                      void *stream);
+/* compute_feasible_sets (:131-164): X [B][N+1][2].                                                          */
+int tpr_feasible_sets_dense_batch(const tpr_dense_problem *p, double *X, void *stream);
+
 /* Replaces Constraint.compute_constraint_params + the dense row build of seidelWrapper.__init__
  * (linear_joint_velocity.py:43-53, linear_joint_acceleration.py:63-104,
  * linear_constraint.py:164-190, cy_seidel_solverwrapper.pyx:474-520):

@@ -47,13 +47,20 @@ class tpr_result(C.Structure):
                 ("status", C.c_void_p)]
 
 
+class tpr_dense_problem(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("nC", C.c_int32), ("flags", C.c_int32),
+                ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p),
+                ("low", C.c_void_p), ("high", C.c_void_p), ("deltas", C.c_void_p),
+                ("sd_start", C.c_void_p), ("sd_end", C.c_void_p)]
+
+
 EXPORTS = (
     "tpr_init", "tpr_device_count", "tpr_last_error", "tpr_version", "tpr_solve_batch",
     "tpr_controllable_sets_batch", "tpr_feasible_sets_batch", "tpr_constraint_params_batch",
     "tpr_solve_stagewise_batch", "tpr_lp1d_batch", "tpr_lp2d_batch", "tpr_solve_batch_timed",
     "tpr_spline_fit_batch", "tpr_const_accel_times_batch", "tpr_const_accel_eval_batch",
     "tpr_solve_desired_duration_batch", "tpr_robust_solve_batch", "tpr_param_spline_batch", "tpr_ppoly_eval_batch",
-    "tpr_reachable_sets_batch",
+    "tpr_reachable_sets_batch", "tpr_solve_dense_batch", "tpr_controllable_sets_dense_batch", "tpr_feasible_sets_dense_batch",
 )
 
 _lib = None
@@ -122,6 +129,13 @@ def load():
         L.tpr_param_spline_batch.argtypes = [P, V, V, V, V, V]
         L.tpr_ppoly_eval_batch.restype = C.c_int
         L.tpr_ppoly_eval_batch.argtypes = [C.c_int, C.c_int, C.c_int, V, V, V, C.c_int, V, C.c_int, V, C.c_int, V]
+        DP = C.POINTER(tpr_dense_problem)
+        L.tpr_solve_dense_batch.restype = C.c_int
+        L.tpr_solve_dense_batch.argtypes = [DP, R, V]
+        L.tpr_controllable_sets_dense_batch.restype = C.c_int
+        L.tpr_controllable_sets_dense_batch.argtypes = [DP, V, V, V, V]
+        L.tpr_feasible_sets_dense_batch.restype = C.c_int
+        L.tpr_feasible_sets_dense_batch.argtypes = [DP, V, V]
         L.tpr_lp1d_batch.restype = C.c_int
         L.tpr_lp1d_batch.argtypes = [C.c_int, C.c_int] + [V] * 10
         L.tpr_lp2d_batch.restype = C.c_int
@@ -196,6 +210,56 @@ def _per_traj(name, arr, B, like, dev):
     if arr.shape != (B,):
         raise ValueError("%s must be a scalar or have shape [B] = [%d], got %s" % (name, B, arr.shape))
     return np.ascontiguousarray(arr)
+
+
+def make_dense_problem(a, b, c, low, high, deltas, sd_start=None, sd_end=None, squared=False, keep=None):
+    """Build a tpr_dense_problem from the arrays of the reference's seidelWrapper (all numpy or all torch-CUDA):
+    a, b, c [B, N+1, nC] (a_arr, b_arr, c_arr: nC counts the two reserved x_next rows), low, high [B, N+1, 2],
+    deltas [N] or [B, N], sd_start / sd_end scalars or [B].  Shapes and dtypes are validated here: the C-ABI takes raw
+    pointers."""
+    dev = is_torch_cuda(a)
+    keep = keep if keep is not None else []
+    if dev:
+        def conv(name, x):
+            if not (hasattr(x, "is_cuda") and x.is_cuda):
+                raise ValueError("%s must be a CUDA tensor like a (mixing host and device arrays is not supported)" % name)
+            check_tensor(name, x, a)
+            return x.contiguous()
+        check_tensor("a", a, a)
+    else:
+        def conv(name, x):
+            return f64(x)
+    a = conv("a", a)
+    if a.ndim != 3:
+        raise ValueError("a must have shape [B, N+1, nC]")
+    B, N1, nC = (int(s) for s in a.shape)
+    N = N1 - 1
+    if N < 1:
+        raise ValueError("dense rows need at least two gridpoints")
+    if not 2 <= nC <= 66:
+        raise ValueError("nC = %d rows per stage (incl. the two x_next rows) is outside 2..66" % nC)
+    b, c = conv("b", b), conv("c", c)
+    low, high = conv("low", low), conv("high", high)
+    for name, arr, shape in (("b", b, (B, N1, nC)), ("c", c, (B, N1, nC)), ("low", low, (B, N1, 2)), ("high", high, (B, N1, 2))):
+        if tuple(arr.shape) != shape:
+            raise ValueError("%s must have shape %s, got %s" % (name, shape, tuple(arr.shape)))
+    deltas = conv("deltas", deltas)
+    if deltas.ndim == 1:
+        if int(deltas.shape[0]) != N:
+            raise ValueError("deltas must have N = %d entries" % N)
+        deltas = (deltas.unsqueeze(0).expand(B, N) if dev else np.broadcast_to(deltas, (B, N)))
+        deltas = deltas.contiguous() if dev else np.ascontiguousarray(deltas)
+    if tuple(deltas.shape) != (B, N):
+        raise ValueError("deltas must have shape [N] or [B, N] = [%d, %d], got %s" % (B, N, tuple(deltas.shape)))
+    p = tpr_dense_problem(B=B, N=N, nC=nC, flags=(DEVICE_PTRS if dev else 0) | (BOUNDARY_SQUARED if squared else 0))
+    keep += [a, b, c, low, high, deltas]
+    p.a, p.b, p.c, p.low, p.high, p.deltas = ptr(a), ptr(b), ptr(c), ptr(low), ptr(high), ptr(deltas)
+    for name, arr in (("sd_start", sd_start), ("sd_end", sd_end)):
+        if arr is not None:
+            arr = _per_traj(name, arr, B, a, dev)
+            keep.append(arr)
+            setattr(p, name, ptr(arr))
+    return p, keep
 
 
 def check_tensor(name, t, like):

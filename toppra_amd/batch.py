@@ -167,6 +167,44 @@ def controllable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interp
     return K
 
 
+def solve_dense_batch(a, b, c, low, high, deltas, sd_start=None, sd_end=None, want_sd=False, squared=False):
+    """compute_parameterization on DENSE rows -- any canonical-linear constraint list, flattened as the reference's
+    seidelWrapper flattens it (cy_seidel_solverwrapper.pyx:425-531; :func:`toppra_amd.solverwrapper.dense_rows` does it for
+    constraint objects): a, b, c [B, N+1, nC], low, high [B, N+1, 2], deltas [N] or [B, N].  Returns the dict of
+    :func:`solve_batch`.  Every stage LP runs the reference's full Seidel iteration: the reference's bits."""
+    _prepare(a)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, sd_start, sd_end, squared=squared)
+    out = {"sd2": _empty(a, (p.B, p.N + 1)), "u": _empty(a, (p.B, p.N)), "K": _empty(a, (p.B, p.N + 1, 2)),
+           "status": _empty(a, (p.B,), "i32")}
+    if want_sd:
+        out["sd"] = _empty(a, (p.B, p.N + 1))
+    r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out.get("sd")), u=_capi.ptr(out["u"]), K=_capi.ptr(out["K"]),
+                         status=_capi.ptr(out["status"]))
+    _capi.check(_capi.load().tpr_solve_dense_batch(C.byref(p), C.byref(r), _stream_ptr(a)))
+    return out
+
+
+def controllable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, squared=False):
+    """compute_controllable_sets(sdmin, sdmax) on dense rows (see :func:`solve_dense_batch`) -> K [B, N+1, 2]."""
+    _prepare(a)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, squared=squared)
+    sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, a)
+    sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, a)
+    K = _empty(a, (p.B, p.N + 1, 2))
+    _capi.check(_capi.load().tpr_controllable_sets_dense_batch(C.byref(p), _capi.ptr(sdmin), _capi.ptr(sdmax), _capi.ptr(K),
+                                                               _stream_ptr(a)))
+    return K
+
+
+def feasible_sets_dense_batch(a, b, c, low, high, deltas):
+    """compute_feasible_sets on dense rows (see :func:`solve_dense_batch`) -> X [B, N+1, 2]."""
+    _prepare(a)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas)
+    X = _empty(a, (p.B, p.N + 1, 2))
+    _capi.check(_capi.load().tpr_feasible_sets_dense_batch(C.byref(p), _capi.ptr(X), _stream_ptr(a)))
+    return X
+
+
 def reachable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpolation=True, want_X=False):
     """compute_reachable_sets(sdmin, sdmax) for B trajectories -> L[B,N+1,2] (and the feasible sets
     X[B,N+1,2] it computes on the way with ``want_X``)."""

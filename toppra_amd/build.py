@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtoppra_hip.so")
-SOURCES = ["tpr_kernels.hip", "tpr_cert_tu.hip", "tpr_robust_tu.hip"]
+SOURCES = ["tpr_kernels.hip", "tpr_cert_tu.hip", "tpr_robust_tu.hip", "tpr_dense_tu.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
@@ -72,7 +72,8 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
             jobs.append((os.path.join(CSRC, "tpr_cert_tu.hip"), os.path.join(tmp, "cert%d.o" % d), ["-DTPR_TU_D=%d" % d] + extra))
         for half in (0, 1):  # the robust (conic) kernels: 1..8 dof + the lane kernel, 9..16 dof
             jobs.append((os.path.join(CSRC, "tpr_robust_tu.hip"), os.path.join(tmp, "robust%d.o" % half), ["-DTPR_TU_HALF=%d" % half]))
-        jobs.sort(key=lambda j: 0 if ("robust" in j[1] or "main" in j[1]) else 1)  # the longest units first
+        jobs.append((os.path.join(CSRC, "tpr_dense_tu.hip"), os.path.join(tmp, "dense.o"), []))  # dense rows: any constraint list
+        jobs.sort(key=lambda j: 0 if ("robust" in j[1] or "main" in j[1] or "dense" in j[1]) else 1)  # the longest units first
 
         def run(job):
             src, obj, extra = job

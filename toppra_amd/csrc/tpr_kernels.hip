@@ -19,6 +19,7 @@
 #include "tpr_spline.hip.inc"
 #include "tpr_param.hip.inc"
 #include "tpr_robust_args.hpp"
+#include "tpr_dense_args.hpp"
 
 #define TPR_TU_CAT3_(a, b) a##b
 #define TPR_TU_CAT3(a, b) TPR_TU_CAT3_(a, b)
@@ -36,8 +37,10 @@
 #define TPR_TU_HALF 2
 #include "tpr_robust_tu.hip"
 #undef TPR_TU_HALF
+#include "tpr_dense_tu.hip"
 #else
 extern "C" {
+__attribute__((visibility("hidden"))) int tpr_tu_dense_launch(const tpr::DenseArgs *, int, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_robust_launch_lo(const tpr::RobustArgs *, size_t, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_robust_launch_hi(const tpr::RobustArgs *, size_t, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_robust_lane_launch(const tpr::RobustArgs *, hipStream_t);
@@ -933,6 +936,79 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
                                dmin, dmax);
         }
     }
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+// ---- dense rows (any canonical-linear constraint list): tpr_dense.hip.inc ----------------------------------------
+namespace {
+int check_dense(const tpr_dense_problem *p) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (!p) return fail(TPR_E_BADARG, "null dense problem");
+    if (p->B < 0 || p->N < 1) return fail(TPR_E_BADARG, "dense problem: B >= 0, N >= 1");
+    if (p->nC < 2 || p->nC > 66) return fail(TPR_E_UNSUPPORTED, "dense problem: 2 <= nC <= 66 rows per stage (incl. the two x_next rows)");
+    if (!p->a || !p->b || !p->c || !p->low || !p->high || !p->deltas) return fail(TPR_E_BADARG, "dense problem: a, b, c, low, high, deltas are required");
+    return TPR_E_OK;
+}
+tpr::DenseArgs stage_dense(const tpr_dense_problem *p, Staging &S) {
+    tpr::DenseArgs A{};
+    const size_t B = (size_t)p->B, N = (size_t)p->N, nC = (size_t)p->nC;
+    A.B = p->B; A.N = p->N; A.nC = p->nC; A.flags = p->flags;
+    A.a = S.in(p->a, B * (N + 1) * nC); A.b = S.in(p->b, B * (N + 1) * nC); A.c = S.in(p->c, B * (N + 1) * nC);
+    A.low = S.in(p->low, B * (N + 1) * 2); A.high = S.in(p->high, B * (N + 1) * 2);
+    A.deltas = S.in(p->deltas, B * N);
+    return A;
+}
+}  // namespace
+
+int tpr_solve_dense_batch(const tpr_dense_problem *p, const tpr_result *r, void *stream_) {
+    if (int rc = check_dense(p)) return rc;
+    if (!r || !r->K) return fail(TPR_E_BADARG, "dense solve: r->K is required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->a));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::DenseArgs A = stage_dense(p, S);
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    A.sd_start = S.in(p->sd_start, B); A.sd_end = S.in(p->sd_end, B);
+    A.sd2 = S.out(r->sd2, B * (N + 1)); A.sd = S.out(r->sd, B * (N + 1)); A.u = S.out(r->u, B * N);
+    A.K = S.out(r->K, B * (N + 1) * 2); A.status = S.out(r->status, B);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (A.B > 0 && tpr_tu_dense_launch(&A, 0, stream) != 0) return fail(TPR_E_UNSUPPORTED, "dense solve: no kernel for this row count");
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_controllable_sets_dense_batch(const tpr_dense_problem *p, const double *sdmin, const double *sdmax, double *K,
+                                      void *stream_) {
+    if (int rc = check_dense(p)) return rc;
+    if (!sdmin || !sdmax || !K) return fail(TPR_E_BADARG, "sdmin/sdmax/K are required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->a));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::DenseArgs A = stage_dense(p, S);
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    A.sd_end = S.in(sdmin, B); A.sd_end_hi = S.in(sdmax, B);
+    A.K = S.out(K, B * (N + 1) * 2);
+    A.backward_only = 1;
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (A.B > 0 && tpr_tu_dense_launch(&A, 0, stream) != 0) return fail(TPR_E_UNSUPPORTED, "dense controllable sets: no kernel for this row count");
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_feasible_sets_dense_batch(const tpr_dense_problem *p, double *X, void *stream_) {
+    if (int rc = check_dense(p)) return rc;
+    if (!X) return fail(TPR_E_BADARG, "X is required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->a));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::DenseArgs A = stage_dense(p, S);
+    A.X = S.out(X, (size_t)p->B * ((size_t)p->N + 1) * 2);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (A.B > 0 && tpr_tu_dense_launch(&A, 1, stream) != 0) return fail(TPR_E_UNSUPPORTED, "dense feasible sets: no kernel for this row count");
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
