@@ -55,6 +55,8 @@ def lib():
         L.orc_wrapper_new.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int]
         L.orc_wrapper_free.restype = None
         L.orc_wrapper_free.argtypes = [C.c_void_p]
+        L.orc_wrapper_new_dense.restype = C.c_void_p
+        L.orc_wrapper_new_dense.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, C.c_int]
         L.orc_solve_stagewise_optim.restype = None
         L.orc_solve_stagewise_optim.argtypes = [C.c_void_p, C.c_int, dp, C.c_double, C.c_double,
                                                 C.c_double, C.c_double, dp]
@@ -228,6 +230,45 @@ class Wrapper:
         st = lib().orc_compute_parameterization(self._h, sd_start, sd_end, _dp(sdd), _dp(sd),
                                                 _dp(xs), _dp(K))
         return st, sdd, sd, xs, K
+
+
+class DenseWrapper(Wrapper):
+    """The oracle's ``seidelWrapper`` for ANY canonical-linear constraint list, from the arrays the reference's
+    ``__init__`` ends up with (cy_seidel_solverwrapper.pyx:474-520): a, b, c [N+1, nC] (rows 0, 1 reserved), low, high
+    [N+1, 2], deltas [N].  Scans as :class:`Wrapper`."""
+
+    def __init__(self, a, b, c, low, high, deltas, solve_lp1d=1):
+        a, b, c, low, high, deltas = (_f64(x) for x in (a, b, c, low, high, deltas))
+        self.N, self.nC = a.shape[0] - 1, a.shape[1]
+        assert b.shape == a.shape and c.shape == a.shape and low.shape == (self.N + 1, 2) and high.shape == (self.N + 1, 2)
+        assert deltas.shape == (self.N,)
+        self._h = lib().orc_wrapper_new_dense(self.N, self.nC, _dp(a), _dp(b), _dp(c), _dp(low), _dp(high), _dp(deltas),
+                                              solve_lp1d)
+
+
+def solve_dense_batch(a, b, c, low, high, deltas, sd_start=None, sd_end=None, want_X=False):
+    """compute_parameterization (+ compute_feasible_sets) on dense rows for B trajectories, one fresh wrapper each:
+    dict(sd2, sd, u, K, status[, X]) -- the checker of tpr_*_dense_batch."""
+    a, b, c, low, high = (_f64(x) for x in (a, b, c, low, high))
+    B, N1, _ = a.shape
+    N = N1 - 1
+    deltas = np.broadcast_to(_f64(deltas), (B, N))
+    sd0 = np.broadcast_to(np.zeros(1) if sd_start is None else _f64(sd_start), (B,))
+    sd1 = np.broadcast_to(np.zeros(1) if sd_end is None else _f64(sd_end), (B,))
+    out = {"sd2": np.full((B, N + 1), np.nan), "sd": np.full((B, N + 1), np.nan), "u": np.full((B, N), np.nan),
+           "K": np.zeros((B, N + 1, 2)), "status": np.zeros(B, dtype=np.int32)}
+    if want_X:
+        out["X"] = np.zeros((B, N + 1, 2))
+    for i in range(B):
+        if want_X:  # a fresh object, as compute_feasible_sets on a new instance
+            out["X"][i] = DenseWrapper(a[i], b[i], c[i], low[i], high[i], np.ascontiguousarray(deltas[i])).compute_feasible_sets()
+        w = DenseWrapper(a[i], b[i], c[i], low[i], high[i], np.ascontiguousarray(deltas[i]))
+        st, sdd, sd, xs, K = w.compute_parameterization(float(sd0[i]), float(sd1[i]))
+        out["status"][i] = st
+        out["K"][i] = K
+        if st != 1:
+            out["sd2"][i], out["sd"][i], out["u"][i] = xs, sd, sdd
+    return out
 
 
 def robust_solve_batch(coef, breaks, grid, vlim, alim, ellipsoid, sd_start=None, sd_end=None,

@@ -14,6 +14,34 @@ def batch_fixtures():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "batch_*.npz")))
 
 
+def dense_fixtures():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "dense_*.npz")))
+
+
+def torque_model(mass, grav, cori):
+    """The inverse dynamics of the dense fixtures (tools/make_golden.py::torque_model: same expression, same bits)."""
+    M = np.diag(mass)
+    return lambda q, qd, qdd: M.dot(qdd) + cori * np.sin(q) * (1 + qd * qd) + grav * np.cos(q)
+
+
+def dense_constraints(fx, b, mod):
+    """The constraint list of trajectory b of a dense fixture, built from the classes of `mod` (toppra_amd.constraint)."""
+    DT = mod.DiscretizationType(int(fx["scheme"]))
+    inv_dyn = torque_model(fx["mass"][b], fx["grav"][b], fx["cori"][b])
+    taulim = np.stack([-fx["taumax"][b], fx["taumax"][b]], axis=1)
+    cons = []
+    for kind in str(fx["kinds"]).split(","):
+        if kind == "vel":
+            cons.append(mod.JointVelocityConstraint(np.stack([-fx["vmax"][b], fx["vmax"][b]], axis=1)))
+        elif kind == "acc":
+            cons.append(mod.JointAccelerationConstraint(np.stack([-fx["amax"][b], fx["amax"][b]], axis=1), discretization_scheme=DT))
+        elif kind == "torque":
+            cons.append(mod.JointTorqueConstraint(inv_dyn, taulim, fx["fric"][b], discretization_scheme=DT))
+        elif kind == "second":
+            cons.append(mod.SecondOrderConstraint.joint_torque_constraint(inv_dyn, taulim, fx["fric"][b], discretization_scheme=DT))
+    return cons
+
+
 def fixture_problem(fx):
     """(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation) of a batch fixture."""
     return (fx["coef"], fx["breaks"], fx["grid"], fx.get("vlim"), fx.get("alim"), fx["sd_start"],

@@ -1,0 +1,135 @@
+"""The dense-row entries (tpr_*_dense_batch: the seidel path for ANY canonical-linear constraint list, rows given as the
+arrays the reference's seidelWrapper builds) against the reference's own outputs for torque / second-order constraints
+(tests/golden/dense_*.npz, tools/make_golden.py), against the oracle on random dense problems, and against the fused
+kernels on the rows of the standard velocity + acceleration problem."""
+import numpy as np
+import pytest
+
+import toppra_amd as ta
+from tests.helpers import assert_same, dense_constraints, dense_fixtures, golden
+from toppra_amd import batch
+from toppra_amd.solverwrapper import dense_rows, hipDenseSeidelWrapper
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(fx):
+    return fx["a"], fx["b"], fx["c"], fx["low"], fx["high"], fx["deltas"]
+
+
+@pytest.mark.parametrize("name", dense_fixtures())
+def test_dense_fixture(gpu, name):
+    """JointTorqueConstraint / SecondOrderConstraint problems solved by the REFERENCE (seidel): K, sd, u, return codes,
+    feasible sets and controllable sets from the fixture's dense rows, bit for bit."""
+    fx = golden(name)
+    got = batch.solve_dense_batch(*_rows(fx), fx["sd_start"], fx["sd_end"], want_sd=True)
+    assert np.array_equal(got["status"], fx["status"])
+    assert_same(got["K"], fx["K"], "K")
+    assert_same(got["sd"], fx["sd"], "sd")
+    assert_same(got["u"], fx["u"], "u")
+    ok = fx["status"] == 0
+    assert_same(got["sd2"][ok], fx["sd"][ok] ** 2, "sd2", atol=1e-8)
+    assert_same(batch.feasible_sets_dense_batch(*_rows(fx)), fx["X"], "X")
+    B = fx["a"].shape[0]
+    Kc = batch.controllable_sets_dense_batch(*_rows(fx), np.full(B, float(fx["sdmin_c"])), np.full(B, float(fx["sdmax_c"])))
+    assert_same(Kc, fx["Kc"], "controllable sets")
+
+
+@pytest.mark.parametrize("name", dense_fixtures())
+def test_dense_fixture_through_the_drop_in_classes(gpu, name):
+    """The same problems through toppra_amd's own classes -- SplineInterpolator, JointTorqueConstraint /
+    SecondOrderConstraint (the user's inverse dynamics evaluated on the host, as in the reference), TOPPRA -- i.e. what a
+    user of the reference would write: the algorithm picks hipDenseSeidelWrapper for constraint lists the fused kernels
+    do not regenerate, and returns the reference's bits."""
+    fx = golden(name)
+    for b in range(fx["a"].shape[0]):
+        path = ta.SplineInterpolator(fx["knots"], fx["way"][b])
+        cons = dense_constraints(fx, b, ta.constraint)
+        rows = dense_rows(cons, path, fx["grid"])
+        for k in ("a", "b", "c", "low", "high"):
+            assert_same(rows[k], fx[k][b], "%s[%d]" % (k, b))
+        inst = ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"])
+        assert isinstance(inst.solver_wrapper, hipDenseSeidelWrapper)
+        # (numpy scalars, as the fixture script passed them: `sd ** 2` is numpy's square there, libm pow for Python floats)
+        sdd, sd, _, K = inst.compute_parameterization(fx["sd_start"][b], fx["sd_end"][b], return_data=True)
+        assert_same(K, fx["K"][b], "K[%d]" % b)
+        if fx["status"][b] == 0:
+            assert_same(sd, fx["sd"][b], "sd[%d]" % b)
+            assert_same(sdd, fx["u"][b], "u[%d]" % b)
+            traj = ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"]).compute_trajectory(fx["sd_start"][b], fx["sd_end"][b])
+            assert traj is not None and traj.duration > 0
+        else:
+            assert sd is None and sdd is None
+        assert_same(ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"]).compute_feasible_sets(), fx["X"][b], "X[%d]" % b)
+        assert_same(ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"]).compute_controllable_sets(
+            float(fx["sdmin_c"]), float(fx["sdmax_c"])), fx["Kc"][b], "Kc[%d]" % b)
+
+
+@pytest.mark.parametrize("B,N,nC,seed", [(64, 30, 2, 1), (200, 25, 7, 2), (96, 40, 34, 3), (64, 20, 35, 4), (40, 16, 66, 5), (33, 1, 12, 6)])
+def test_random_dense_problems_vs_oracle(gpu, oracle, B, N, nC, seed):
+    """Random dense rows -- any row count up to the 66 the slot layouts hold (34 / 35: the switch from 8 to 16 lanes per
+    trajectory), rows of mixed orientation, boxes on u, infeasible stages, failing forward scans -- against the oracle's
+    seidelWrapper on the same arrays: K, sd2, u, return codes, feasible sets, bit for bit."""
+    rng = np.random.default_rng(seed)
+    ang = rng.uniform(0, 2 * np.pi, size=(B, N + 1, nC))
+    a, b = np.cos(ang), 0.3 * np.sin(ang)
+    c = -(0.5 + 2.0 * rng.random((B, N + 1, nC)))           # the origin strictly inside every row
+    c[rng.random((B, N + 1, nC)) < 0.4 / ((N + 1) * nC)] = 0.3  # ... except in a third of the trajectories: infeasible or tight stages
+    a[:, :, :2] = b[:, :, :2] = c[:, :, :2] = 0.0            # the reserved x_next rows
+    low = np.stack([np.full((B, N + 1), -1e8), np.zeros((B, N + 1))], axis=-1)
+    high = np.stack([np.full((B, N + 1), 1e8), 2.0 + rng.random((B, N + 1))], axis=-1)
+    tight = rng.random(B) < 0.3                              # a box on u for some trajectories (ubound)
+    low[tight, :, 0], high[tight, :, 0] = -3.0, 3.0
+    deltas = 0.02 + 0.03 * rng.random((B, N))
+    sd0, sd1 = 0.5 * rng.random(B), 0.5 * rng.random(B)
+    sd0[::7] = 5.0                                           # outside the controllable set (x <= 3)
+    got = batch.solve_dense_batch(a, b, c, low, high, deltas, sd0, sd1, want_sd=True)
+    want = oracle.solve_dense_batch(a, b, c, low, high, deltas, sd0, sd1, want_X=True)
+    assert np.array_equal(got["status"], want["status"]) and len(set(want["status"])) >= 2
+    assert_same(got["K"], want["K"], "K")
+    done = want["status"] == 0
+    for k in ("sd2", "sd", "u"):
+        assert_same(got[k][done], want[k][done], k)
+    assert np.isnan(got["sd2"][want["status"] == 1]).all()
+    assert_same(batch.feasible_sets_dense_batch(a, b, c, low, high, deltas), want["X"], "X")
+
+
+@pytest.mark.parametrize("B,d,N,interp,vel", [(4096, 7, 200, True, True), (300, 7, 60, False, True), (256, 3, 50, True, False),
+                                              (64, 9, 40, True, True), (32, 16, 25, True, True), (200, 5, 3, True, True)])
+def test_dense_rows_of_the_standard_problem_give_the_fused_kernels_bits(gpu, B, d, N, interp, vel):
+    """tpr_constraint_params_batch writes the rows of the velocity + acceleration problem as seidelWrapper would; fed back
+    as dense arrays they must give what the fused kernels (which never materialise them, and answer most LPs from
+    certificates) give: parameterization, controllable sets from an interval, feasible sets -- every bit."""
+    rng = np.random.default_rng(B + d)
+    data = batch.make_synthetic_batch(B, d, N, seed=100 + d + N)
+    vlim = data["vlim"] if vel else None
+    sd0 = 0.3 * rng.random(B) * (rng.random(B) < 0.5)
+    sd1 = 0.3 * rng.random(B) * (rng.random(B) < 0.5)
+    args = (data["coef"], data["breaks"], data["grid"], vlim, data["alim"])
+    rows = batch.constraint_params_batch(*args, interp)
+    dense = (rows["a"], rows["b"], rows["c"], rows["low"], rows["high"], np.diff(data["grid"]))
+    ref = batch.solve_batch(*args, sd0, sd1, interp, want_sd=True)
+    got = batch.solve_dense_batch(*dense, sd0, sd1, want_sd=True)
+    for k in ("K", "sd2", "sd", "u"):
+        assert_same(got[k], ref[k], k)
+    assert np.array_equal(got["status"], ref["status"])
+    assert_same(batch.controllable_sets_dense_batch(*dense, 0.1 * sd1, sd1 + 0.2),
+                batch.controllable_sets_batch(*args, 0.1 * sd1, sd1 + 0.2, interp), "controllable sets")
+    assert_same(batch.feasible_sets_dense_batch(*dense), batch.feasible_sets_batch(*args, interp), "feasible sets")
+
+
+def test_dense_entries_on_device_tensors_and_bad_arguments(gpu):
+    import torch
+    fx = golden("dense_torque_d5_N40_collocation")
+    dev = torch.device("cuda", 0)
+    rows = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in _rows(fx)]
+    got = batch.solve_dense_batch(*rows, torch.from_numpy(fx["sd_start"]).to(dev), torch.from_numpy(fx["sd_end"]).to(dev), want_sd=True)
+    assert_same(got["sd"].cpu().numpy(), fx["sd"], "sd (device tensors)")
+    assert_same(batch.feasible_sets_dense_batch(*rows).cpu().numpy(), fx["X"], "X (device tensors)")
+    a = np.zeros((2, 5, 67))
+    with pytest.raises(ValueError):
+        batch.solve_dense_batch(a, a, a, np.zeros((2, 5, 2)), np.ones((2, 5, 2)), np.ones(4))
+    with pytest.raises(ValueError):
+        batch.solve_dense_batch(a[:, :, :9], a[:, :, :8], a[:, :, :9], np.zeros((2, 5, 2)), np.ones((2, 5, 2)), np.ones(4))
+    with pytest.raises(ValueError):
+        batch.solve_dense_batch(a[:, :, :9], a[:, :, :9], a[:, :, :9], np.zeros((2, 5, 2)), np.ones((2, 5, 2)), np.ones(3))

@@ -4,7 +4,7 @@ reference itself is not importable (the GPU box)."""
 import numpy as np
 import pytest
 
-from tests.helpers import assert_same, batch_fixtures, fixture_problem, golden
+from tests.helpers import assert_same, batch_fixtures, dense_constraints, dense_fixtures, fixture_problem, golden
 
 
 @pytest.mark.parametrize("name", batch_fixtures())
@@ -126,3 +126,56 @@ def test_oracle_wrapper_state_across_passes(oracle):
             assert np.array_equal(K, fx["K" + tag][b], equal_nan=True), (b, tag)
             if st == 0:
                 assert np.array_equal(sd, fx["sd" + tag][b]) and np.array_equal(sdd, fx["u" + tag][b]), (b, tag)
+
+
+@pytest.mark.parametrize("name", dense_fixtures())
+def test_dense_fixture(oracle, name):
+    """Constraint lists beyond velocity + acceleration (JointTorqueConstraint, SecondOrderConstraint): the oracle's
+    seidelWrapper on the dense rows of the fixture -- the reference's constraint objects flattened by
+    toppra_amd.solverwrapper.dense_rows -- reproduces what the REFERENCE returned for those objects: K, sd, u, return
+    codes, feasible sets, controllable sets, bit for bit.  This pins both the dense oracle and the row assembly."""
+    fx = golden(name)
+    got = oracle.solve_dense_batch(fx["a"], fx["b"], fx["c"], fx["low"], fx["high"], fx["deltas"], fx["sd_start"], fx["sd_end"],
+                                   want_X=True)
+    assert np.array_equal(got["status"], fx["status"])
+    assert_same(got["K"], fx["K"], "K")
+    ok = fx["status"] == 0
+    assert_same(got["sd"][ok], fx["sd"][ok], "sd")
+    assert_same(got["u"][ok], fx["u"][ok], "u")
+    assert np.isnan(fx["sd"][fx["status"] == 1]).all()
+    assert_same(got["X"], fx["X"], "X")
+    for b in range(fx["a"].shape[0]):
+        w = oracle.DenseWrapper(fx["a"][b], fx["b"][b], fx["c"][b], fx["low"][b], fx["high"][b], fx["deltas"])
+        assert_same(w.compute_controllable_sets(float(fx["sdmin_c"]), float(fx["sdmax_c"])), fx["Kc"][b], "Kc[%d]" % b)
+
+
+def test_dense_rows_from_the_mirror_constraint_classes():
+    """toppra_amd's own SecondOrderConstraint / JointTorqueConstraint (host numpy through the user's inverse dynamics, as in
+    the reference) + dense_rows against the rows the REFERENCE's constraint objects gave (fixtures without a velocity /
+    acceleration constraint need no GPU): the same bits."""
+    import toppra_amd as ta
+    from toppra_amd.solverwrapper import dense_rows
+    fx = golden("dense_torque_only_d3_N30")
+    for b in range(fx["a"].shape[0]):
+        path = ta.SplineInterpolator(fx["knots"], fx["way"][b])
+        rows = dense_rows(dense_constraints(fx, b, ta.constraint), path, fx["grid"])
+        for k in ("a", "b", "c", "low", "high"):
+            assert_same(rows[k], fx[k][b], "%s[%d]" % (k, b))
+        assert_same(rows["deltas"], fx["deltas"], "deltas")
+    # the second-order class with per-gridpoint F, g (not `identical`), Collocation and Interpolation, against the
+    # identical-F torque class on the same model: the same rows
+    rng = np.random.default_rng(0)
+    d = 4
+    path = ta.SplineInterpolator(np.linspace(0, 1, 5), rng.standard_normal((5, d)))
+    grid = np.linspace(0, 1, 21)
+    from tests.helpers import torque_model
+    inv_dyn = torque_model(1 + rng.random(d), rng.standard_normal(d), rng.standard_normal(d))
+    taulim = np.stack([-5 - rng.random(d), 5 + rng.random(d)], axis=1)
+    fric = 0.1 * rng.random(d)
+    for scheme in (0, 1):
+        DT = ta.constraint.DiscretizationType(scheme)
+        r1 = dense_rows([ta.constraint.JointTorqueConstraint(inv_dyn, taulim, fric, discretization_scheme=DT)], path, grid)
+        r2 = dense_rows([ta.constraint.SecondOrderConstraint.joint_torque_constraint(inv_dyn, taulim, fric, discretization_scheme=DT)], path, grid)
+        assert r1["nC"] == r2["nC"] == 2 + (4 if scheme else 2) * d
+        for k in ("a", "b", "c"):
+            np.testing.assert_allclose(r1[k], r2[k], rtol=0, atol=1e-13)

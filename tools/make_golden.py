@@ -424,6 +424,75 @@ def pow_fixture(name="pow_boundary_d3_N40", B=16, d=3, N=40, seed=61):
           int((out["K"][:, N, 0] != out["sd_end"] * out["sd_end"]).sum()))
 
 
+def torque_model(mass, grav, cori):
+    """A small rigid-body-like inverse dynamics tau(q, qd, qdd) = M qdd + cori sin(q) (1 + qd^2) + grav cos(q), rebuilt
+    from the three stored vectors by tests/helpers.py::torque_model (same expression, same bits)."""
+    M = np.diag(mass)
+    return lambda q, qd, qdd: M.dot(qdd) + cori * np.sin(q) * (1 + qd * qd) + grav * np.cos(q)
+
+
+def dense_fixture(name, B, d, N, seed, kinds, scheme, sd_mode="zero"):
+    """Constraint lists beyond velocity + acceleration, the ones the dense-row entries (tpr_*_dense_batch) serve:
+    kinds is a tuple of "vel", "acc", "torque" (JointTorqueConstraint), "second" (SecondOrderConstraint.joint_torque_constraint).
+    Stored: the model's numbers (so that the GPU tests rebuild the constraint objects with toppra_amd's own classes), the
+    reference's K / sd / u / status / feasible sets / controllable sets, and the dense rows of the reference's constraint
+    objects flattened by toppra_amd.solverwrapper.dense_rows (host numpy; the oracle run on them reproduces the
+    reference's outputs bit for bit: tests/test_oracle_golden.py)."""
+    from toppra_amd.solverwrapper import dense_rows
+    rng = np.random.default_rng(seed)
+    knots, grid = np.linspace(0, 1, 5), np.linspace(0, 1, N + 1)
+    way = rng.standard_normal((B, 5, d))
+    mass, grav, cori = 1.0 + rng.random((B, d)), 0.5 * rng.standard_normal((B, d)), 0.3 * rng.standard_normal((B, d))
+    taumax = 6.0 + 6.0 * rng.random((B, d))
+    fric = 0.1 * rng.random((B, d))
+    vmax, amax = 10 + 20 * rng.random((B, d)), 10 + 2 * rng.random((B, d))
+    sd0, sd1 = np.zeros(B), np.zeros(B)
+    if sd_mode == "random":
+        sd0, sd1 = 0.15 * rng.random(B), 0.15 * rng.random(B)
+        sd0[::4] = 6.0  # uncontrollable starts
+    DT = constraint.DiscretizationType(scheme)
+    out = {k: [] for k in ("a", "b", "c", "low", "high", "K", "sd", "u", "status", "X", "Kc")}
+    for b in range(B):
+        path = ta.SplineInterpolator(knots, way[b])
+        inv_dyn = torque_model(mass[b], grav[b], cori[b])
+        taulim = np.stack([-taumax[b], taumax[b]], axis=1)
+        cons = []
+        for kind in kinds:
+            if kind == "vel":
+                cons.append(constraint.JointVelocityConstraint(np.stack([-vmax[b], vmax[b]], axis=1)))
+            elif kind == "acc":
+                cons.append(constraint.JointAccelerationConstraint(np.stack([-amax[b], amax[b]], axis=1), discretization_scheme=DT))
+            elif kind == "torque":
+                cons.append(constraint.JointTorqueConstraint(inv_dyn, taulim, fric[b], discretization_scheme=DT))
+            elif kind == "second":
+                cons.append(constraint.SecondOrderConstraint.joint_torque_constraint(inv_dyn, taulim, fric[b], discretization_scheme=DT))
+        inst = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        sdd, sd, _, K = inst.compute_parameterization(sd0[b], sd1[b], return_data=True)
+        st = STATUS[inst.problem_data.return_code]
+        if sd is None:
+            sd, sdd = np.full(N + 1, np.nan), np.full(N, np.nan)
+        out["K"].append(K); out["sd"].append(sd); out["u"].append(sdd); out["status"].append(st)
+        out["X"].append(algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_feasible_sets())
+        out["Kc"].append(algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_controllable_sets(0.05, 0.4))
+        rows = dense_rows(cons, path, grid)
+        for k in ("a", "b", "c", "low", "high"):
+            out[k].append(rows[k])
+    rec = {k: np.stack(v) for k, v in out.items()}
+    rec["status"] = rec["status"].astype(np.int32)
+    rec.update(deltas=np.diff(grid), grid=grid, knots=knots, way=way, mass=mass, grav=grav, cori=cori, taumax=taumax, fric=fric,
+               vmax=vmax, amax=amax, sd_start=sd0, sd_end=sd1, scheme=np.array(scheme), kinds=np.array(",".join(kinds)),
+               sdmin_c=np.array(0.05), sdmax_c=np.array(0.4))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, "nC", rec["a"].shape[2], "status counts", np.bincount(rec["status"], minlength=3))
+
+
+def dense_fixtures():
+    dense_fixture("dense_torque_d5_N40_collocation", 8, 5, 40, seed=71, kinds=("vel", "torque"), scheme=0)
+    dense_fixture("dense_vel_acc_second_d6_N50", 6, 6, 50, seed=72, kinds=("vel", "acc", "second"), scheme=1, sd_mode="random")
+    dense_fixture("dense_torque_only_d3_N30", 8, 3, 30, seed=73, kinds=("torque",), scheme=1, sd_mode="random")
+    dense_fixture("dense_second_d7_N60_collocation", 4, 7, 60, seed=74, kinds=("vel", "acc", "second"), scheme=0)
+
+
 def high_dof_fixtures():
     """round 3: the slim blocks of kernel family 3 (9..13 dof: 11 with boundary velocities, 13 with Collocation) and the
     two / three row slots per lane of family 4 above 16 dof (24, 32 dof)"""
@@ -442,6 +511,9 @@ if __name__ == "__main__":
     if "--reachable-only" in sys.argv:
         reachable_fixture()
         reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)
+        raise SystemExit(0)
+    if "--dense-only" in sys.argv:
+        dense_fixtures()
         raise SystemExit(0)
     if "--high-dof-only" in sys.argv:
         high_dof_fixtures()
@@ -466,6 +538,7 @@ if __name__ == "__main__":
     batch_fixture("batch_d14_N40_boundary", 6, 14, 40, seed=14, sd_mode="random")
     batch_fixture("batch_d16_N30", 4, 16, 30, seed=15)
     high_dof_fixtures()
+    dense_fixtures()
     reachable_fixture()
     reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)
     reuse_fixture()

@@ -16,7 +16,7 @@ from . import batch as _batch
 from . import exceptions
 from . import interpolator as _interp
 from .constants import SMALL
-from .solverwrapper import hipRobustWrapper, hipSeidelWrapper
+from .solverwrapper import hipDenseSeidelWrapper, hipRobustWrapper, hipSeidelWrapper
 
 logger = logging.getLogger(__name__)
 
@@ -126,8 +126,14 @@ class ReachabilityAlgorithm(ParameterizationAlgorithm):
             self.solver_wrapper = hipRobustWrapper(self.constraints, self.path, self.gridpoints)
         else:
             assert solver_wrapper.lower() in self._SOLVERS, "Solver {:} not found".format(solver_wrapper)
-            self.solver_wrapper = hipSeidelWrapper(self.constraints, self.path, self.gridpoints,
-                                                   solve_lp1d=True)
+            try:  # velocity + acceleration limits: rows regenerated on the GPU from the spline table (the fused kernels)
+                self.solver_wrapper = hipSeidelWrapper(self.constraints, self.path, self.gridpoints,
+                                                       solve_lp1d=True)
+            except NotImplementedError:
+                # any other canonical-linear list (second-order / torque constraints, the reference's own or hand-written
+                # constraint objects): parameters from the constraints' callbacks, the scans on the dense-row entries
+                self.solver_wrapper = hipDenseSeidelWrapper(self.constraints, self.path, self.gridpoints,
+                                                            solve_lp1d=True)
 
     def compute_feasible_sets(self):
         """X[N+1, 2]: feasible squared velocities per gridpoint (NaN where infeasible)."""

@@ -148,6 +148,121 @@ class JointAccelerationConstraint(LinearConstraint):
         return a, b, np.zeros_like(a), F, np.concatenate([g1, g1]), None, None
 
 
+def colloc_to_interpolate(a, b, c, F, g, xbound, ubound, gridpoints, identical=False):
+    """First-order interpolation form of canonical-linear parameters (linear_constraint.py:84-192): the constraint of
+    stage i is imposed at gridpoint i and, through x_{i+1} = x_i + 2 delta_i u_i, at gridpoint i + 1 -- the row blocks
+    [a_i | a_{i+1} + 2 delta_i b_{i+1}], [b_i | b_{i+1}], [c_i | c_{i+1}] against blkdiag(F_i, F_{i+1}), [g_i | g_{i+1}];
+    the last stage repeats itself.  ``identical``: one F (m x d) and g (m) for every gridpoint.  Host numpy, like the
+    reference: these parameters come from user callbacks (inverse dynamics) and feed the dense-row entries
+    (tpr_*_dense_batch)."""
+    if a is None:
+        return None, None, None, None, None, xbound, ubound
+    a, b, c = (np.asarray(v, dtype=float) for v in (a, b, c))
+    two_delta = 2 * np.diff(np.asarray(gridpoints, dtype=float)).reshape(-1, 1)
+    nxt = lambda v: np.concatenate((v[1:], v[-1:]), axis=0)  # noqa: E731  (gridpoint i + 1; the last one repeats itself)
+    a_next = np.concatenate((a[1:] + two_delta * b[1:], a[-1:]), axis=0)
+    a2, b2, c2 = np.hstack((a, a_next)), np.hstack((b, nxt(b))), np.hstack((c, nxt(c)))
+    F, g = np.asarray(F, dtype=float), np.asarray(g, dtype=float)
+    if identical:
+        m, d = F.shape
+        F2 = np.zeros((2 * m, 2 * d))
+        F2[:m, :d] = F
+        F2[m:, d:] = F
+        g2 = np.concatenate((g, g))
+    else:
+        n1, m, d = F.shape
+        F2 = np.zeros((n1, 2 * m, 2 * d))
+        F2[:, :m, :d] = F
+        F2[:, m:, d:] = nxt(F)
+        g2 = np.hstack((g, nxt(g)))
+    return a2, b2, c2, F2, g2, xbound, ubound
+
+
+def _second_order_coefficients(inv_dyn, q, qs, qss):
+    """(a, b, c)[N+1, m] of  w = a(s) sdd + b(s) sd^2 + c(s)  from an inverse-dynamics callback by substitution:
+    c = tau(q, 0, 0), a = tau(q, 0, q') - c, b = tau(q, q', q'') - c (linear_second_order.py:154-162)."""
+    zero = np.zeros(q.shape[1])
+    c = np.array([inv_dyn(q_i, zero, zero) for q_i in q], dtype=float)
+    a = np.array([inv_dyn(q_i, zero, qs_i) for q_i, qs_i in zip(q, qs)], dtype=float) - c
+    b = np.array([inv_dyn(q_i, qs_i, qss_i) for q_i, qs_i, qss_i in zip(q, qs, qss)], dtype=float) - c
+    return a, b, c
+
+
+class SecondOrderConstraint(LinearConstraint):
+    """General second-order constraint  A(q) qdd + qd^T B(q) qd + C(q) = w,  F(q) w <= g(q)  given by an inverse-dynamics
+    callback ``inv_dyn(q, qd, qdd) -> w`` and callbacks ``constraint_F(q)``, ``constraint_g(q)``
+    (linear_second_order.py:11-173); ``custom_term(path, s)`` is added to c (joint friction).  The parameters are
+    evaluated on the host, through the user's callbacks, as in the reference; the solve runs on the dense-row entries
+    (hipDenseSeidelWrapper)."""
+
+    def __init__(self, inv_dyn, constraint_F, constraint_g, dof, custom_term=None,
+                 discretization_scheme=DiscretizationType.Interpolation):
+        super(SecondOrderConstraint, self).__init__()
+        self.set_discretization_type(discretization_scheme)
+        self.inv_dyn = inv_dyn
+        self.constraint_F = constraint_F
+        self.constraint_g = constraint_g
+        self.dof = dof
+        self.custom_term = custom_term
+        self._format_string = "    Kind: Generalized Second-order constraint\n    Dimension:\n        F in R^({:d}, {:d})\n".format(
+            *np.shape(constraint_F(np.zeros(dof))))
+
+    @classmethod
+    def joint_torque_constraint(cls, inv_dyn, taulim, joint_friction, **kwargs):
+        """Joint torque bounds taulim [dof, 2] with dry friction joint_friction [dof] (sign(q') * friction added to c)."""
+        taulim = np.asarray(taulim, dtype=float)
+        dof = taulim.shape[0]
+        F = np.vstack((np.eye(dof), -np.eye(dof)))
+        g = np.concatenate((taulim[:, 1], -taulim[:, 0]))
+        return cls(inv_dyn, lambda _q: F, lambda _q: g, dof,
+                   lambda path, s: np.sign(path(s, 1)) * joint_friction, **kwargs)
+
+    def compute_constraint_params(self, path, gridpoints, *args, **kwargs):
+        _check_dof(self, path)
+        gridpoints = np.asarray(gridpoints, dtype=float)
+        q = np.asarray(path(gridpoints))
+        a, b, c = _second_order_coefficients(self.inv_dyn, q, np.asarray(path(gridpoints, 1)), np.asarray(path(gridpoints, 2)))
+        F = np.array([self.constraint_F(q_i) for q_i in q], dtype=float)
+        g = np.array([self.constraint_g(q_i) for q_i in q], dtype=float)
+        if self.custom_term is not None:
+            for i, s in enumerate(gridpoints):
+                c[i] = c[i] + self.custom_term(path, s)
+        if self.discretization_type == DiscretizationType.Collocation:
+            return a, b, c, F, g, None, None
+        return colloc_to_interpolate(a, b, c, F, g, None, None, gridpoints)
+
+
+class JointTorqueConstraint(LinearConstraint):
+    """Joint torque bounds  tau_lim[:, 0] <= inv_dyn(q, qd, qdd) + fs_coef * sign(qd) <= tau_lim[:, 1]
+    (joint_torque.py:10-116): one F = [I; -I], g = [tau_max; -tau_min] for every gridpoint (``identical``)."""
+
+    def __init__(self, inv_dyn, tau_lim, fs_coef, discretization_scheme=DiscretizationType.Collocation):
+        super(JointTorqueConstraint, self).__init__()
+        self.inv_dyn = inv_dyn
+        self.tau_lim = np.array(tau_lim, dtype=float)
+        assert self.tau_lim.ndim == 2 and self.tau_lim.shape[1] == 2, "Wrong input shape."
+        self.fs_coef = np.array(fs_coef, dtype=float)
+        self.dof = self.tau_lim.shape[0]
+        self.set_discretization_type(discretization_scheme)
+        self.identical = True
+        self._format_string = "    Torque limit: \n" + "".join(
+            "      J{:d}: {:}\n".format(i + 1, lim) for i, lim in enumerate(self.tau_lim))
+
+    def compute_constraint_params(self, path, gridpoints, *args, **kwargs):
+        _check_dof(self, path)
+        gridpoints = np.asarray(gridpoints, dtype=float)
+        qs = np.asarray(path(gridpoints, 1))
+        a, b, c = _second_order_coefficients(self.inv_dyn, np.asarray(path(gridpoints)), qs, np.asarray(path(gridpoints, 2)))
+        for k in range(self.dof):  # dry friction
+            c[:, k] += self.fs_coef[k] * np.sign(qs[:, k])
+        eye = np.eye(self.dof)
+        F = np.vstack((eye, -eye))
+        g = np.concatenate((self.tau_lim[:, 1], -self.tau_lim[:, 0]))
+        if self.discretization_type == DiscretizationType.Collocation:
+            return a, b, c, F, g, None, None
+        return colloc_to_interpolate(a, b, c, F, g, None, None, gridpoints, identical=True)
+
+
 class ConicConstraint(Constraint):
     """Base class of canonical conic constraints (conic_constraint.py:6-44)."""
 

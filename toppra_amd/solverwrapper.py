@@ -183,6 +183,90 @@ class hipSeidelWrapper(SolverWrapper):
         return out[0]
 
 
+def dense_rows(constraint_list, path, path_discretization):
+    """The arrays seidelWrapper.__init__ builds from ANY list of canonical-linear constraints
+    (cy_seidel_solverwrapper.pyx:455-520): dict(a, b, c [N+1, nC] -- rows 0, 1 reserved for the x_next pair, then one
+    block of rows F a, F b, F c - g per constraint --, low, high [N+1, 2] -- the +-1e8 variable box tightened by the
+    constraints' ubound / xbound --, deltas [N], params).  Host numpy with the reference's own calls (``a.dot(F.T)``
+    for identical constraints, one ``F_i.dot(a_i)`` per gridpoint otherwise), so the rows are the reference's bits for
+    the same numpy; the parameters themselves come from the constraints' (user) callbacks."""
+    grid = np.array(path_discretization, dtype=np.float64)
+    n1 = len(grid)
+    params, blocks = [], []
+    low, high = np.full((n1, 2), -1e8), np.full((n1, 2), 1e8)  # VAR_MIN / VAR_MAX (:22-23)
+    for con in constraint_list:
+        if getattr(con.get_constraint_type(), "value", None) != 0:
+            raise NotImplementedError("the seidel path handles CanonicalLinear constraints only")
+        a, b, c, F, g, ubound, xbound = con.compute_constraint_params(path, grid)
+        params.append((a, b, c, F, g, ubound, xbound))
+        if a is not None:
+            if getattr(con, "identical", False):
+                blocks.append((a.dot(F.T), b.dot(F.T), c.dot(F.T) - g))
+            else:
+                rows = [(np.dot(F[i], a[i]), np.dot(F[i], b[i]), np.dot(F[i], c[i]) - g[i]) for i in range(n1)]
+                blocks.append(tuple(np.array([r[k] for r in rows]) for k in range(3)))
+        for col, bound in ((0, ubound), (1, xbound)):
+            if bound is not None:  # dbl_max(a, b) = a if a > b else b (:43-50)
+                low[:, col] = np.where(low[:, col] > bound[:, 0], low[:, col], bound[:, 0])
+                high[:, col] = np.where(high[:, col] < bound[:, 1], high[:, col], bound[:, 1])
+    nC = 2 + sum(blk[0].shape[1] for blk in blocks)
+    out = {k: np.zeros((n1, nC)) for k in ("a", "b", "c")}
+    col = 2
+    for blk in blocks:
+        m = blk[0].shape[1]
+        for k, arr in zip(("a", "b", "c"), blk):
+            out[k][:, col:col + m] = arr
+        col += m
+    out.update(low=low, high=high, deltas=grid[1:] - grid[:-1], nC=nC, params=params)
+    return out
+
+
+class hipDenseSeidelWrapper(SolverWrapper):
+    """seidelWrapper for ANY list of canonical-linear constraints (SecondOrderConstraint, JointTorqueConstraint, the
+    reference's own constraint objects, hand-written ones): the constraints' parameters are evaluated on the host, as in
+    the reference, flattened by :func:`dense_rows`, and the passes run on the dense-row entries of the library
+    (tpr_*_dense_batch: rows across lanes, the reference's full Seidel iteration).  Every pass starts from a fresh
+    object's warm-start state (compute_trajectory on a new instance -- the usual flow -- returns the reference's bits)."""
+
+    def __init__(self, constraint_list, path, path_discretization, solve_lp1d=1):
+        self.constraints = constraint_list
+        self.path = path
+        self.path_discretization = np.array(path_discretization, dtype=np.float64)
+        self.N = len(self.path_discretization) - 1
+        self.nV = 2
+        for c in constraint_list:
+            if c.get_dof() != path.dof:
+                raise ValueError("Wrong dimension: constraint dof ({:d}) not equal to path dof ({:d})".format(
+                    c.get_dof(), path.dof))
+        rows = dense_rows(constraint_list, path, self.path_discretization)
+        self.deltas = rows["deltas"]
+        self.nC = rows["nC"]
+        self.params = rows["params"]
+        if self.nC > 66:
+            raise NotImplementedError("%d constraint rows per stage: the dense-row kernels hold 66" % self.nC)
+        self._rows = tuple(np.ascontiguousarray(rows[k][None]) for k in ("a", "b", "c", "low", "high")) + (self.deltas,)
+
+    def controllable_sets(self, sdmin, sdmax):
+        return batch.controllable_sets_dense_batch(*self._rows, np.array([sdmin ** 2], dtype=np.float64),
+                                                   np.array([sdmax ** 2], dtype=np.float64), squared=True)[0]
+
+    def feasible_sets(self):
+        return batch.feasible_sets_dense_batch(*self._rows)[0]
+
+    def parameterization(self, sd_start, sd_end):
+        out = batch.solve_dense_batch(*self._rows, np.array([sd_start ** 2], dtype=np.float64),
+                                      np.array([sd_end ** 2], dtype=np.float64), want_sd=True, squared=True)
+        res = {k: v[0] for k, v in out.items() if k != "status"}
+        res["status"] = int(out["status"][0])
+        return res
+
+    def reachable_sets(self, sdmin, sdmax):
+        raise NotImplementedError("reachable sets are implemented for velocity + acceleration constraints (hipSeidelWrapper)")
+
+    def parameterization_sd(self, sd_start, sd_end, desired_duration, atol=1e-5):
+        raise NotImplementedError("TOPPRAsd is implemented for velocity + acceleration constraints (hipSeidelWrapper)")
+
+
 class hipRobustWrapper(SolverWrapper):
     """Wrapper for [JointVelocityConstraint (optional), RobustLinearConstraint(JointAccelerationConstraint)]
     problems -- the role ``ecosWrapper`` plays in the reference (ecos_solverwrapper.py:14-207).
