@@ -291,6 +291,24 @@ def baseline_configs(torch, tb, dev):
     res["large_batch262144_d7_N200"] = dict(kernel(262144, 7, 200, reps=3),
                                             note="four rounds of one wave per SIMD: the kernel has no two-waves-per-SIMD variant (DESIGN.md 3.8)")
     res["d12_batch65536_N200"] = dict(kernel(65536, 12, 200, reps=3), note="kernel family 3 at 12 dof: slim blocks, four per CU (DESIGN.md 3.2)")
+    # dense rows (any canonical-linear constraint list): the headline problem's own rows materialised as
+    # seidelWrapper would hold them (144 KB per trajectory) and solved from those arrays -- the HBM-heavy form of the path
+    datad = tb.make_synthetic_batch(65536, 7, 200)
+    dvd = dev_args(datad)
+    rows = tb.constraint_params_batch(*dvd)
+    dense = (rows["a"], rows["b"], rows["c"], rows["low"], rows["high"], dvd[2][1:] - dvd[2][:-1])
+    same = bool(torch.equal(torch.nan_to_num(tb.solve_dense_batch(*dense)["sd2"], nan=-7.0),
+                            torch.nan_to_num(tb.solve_batch(*dvd)["sd2"], nan=-7.0)))
+    msd = wall(lambda: tb.solve_dense_batch(*dense), 3)
+    row_bytes = 2 * 8 * 65536 * (201 * (3 * 30 + 4) + 200)  # rows + boxes + deltas, read by the backward and by the forward scan
+    res["dense_rows_batch65536_d7_N200"] = {
+        "batch": 65536, "rows_per_stage": 30, "gridpoints": 200, "ms": msd, "trajectories_per_s": 65536 / msd * 1e3,
+        "row_bytes_read": row_bytes, "GBps": row_bytes / (msd * 1e-3) / 1e9, "hbm_frac_of_8TBps_peak": row_bytes / (msd * 1e-3) / 8e12,
+        "identical_bits_to_the_fused_path": same,
+        "note": "tpr_solve_dense_batch: every stage LP through the reference's full Seidel iteration on rows read from HBM "
+                "(the entry that serves torque / second-order / hand-written constraints); bound by the iteration's instruction "
+                "count like the fused strict mode, the row traffic hides behind it"}
+    del rows, dense, dvd
     # PCIe-inclusive: numpy in -> numpy out through the host-buffer entry (H2D 59 MB, kernel, D2H)
     datah = tb.make_synthetic_batch(65536, 7, 200)
     hargs = [datah[k] for k in ("coef", "breaks", "grid", "vlim", "alim")]

@@ -70,11 +70,12 @@ def test_product_never_imports_oracle():
 
 
 def test_integration_stub_declares_the_same_structs():
-    """The ctypes stub INTEGRATION.md hands to a toppra maintainer must declare tpr_problem / tpr_result field for field
+    """The ctypes stub INTEGRATION.md hands to a toppra maintainer must declare tpr_problem / tpr_result / tpr_dense_problem field for field
     as the package's own binding does (a struct that is one pointer short makes the library read past its end)."""
     from toppra_amd import _capi
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    for name, cls in (("tpr_problem", _capi.tpr_problem), ("tpr_result", _capi.tpr_result)):
+    for name, cls in (("tpr_problem", _capi.tpr_problem), ("tpr_result", _capi.tpr_result),
+                      ("tpr_dense_problem", _capi.tpr_dense_problem)):
         block = re.search(r"class %s\(C\.Structure\):\s*_fields_ = \[(.*?)\]\s*(#[^\n]*)?\n\n" % name, text, re.S)
         assert block, name
         fields = re.findall(r'\("(\w+)",\s*C\.(\w+)\)', block.group(1))

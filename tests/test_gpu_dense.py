@@ -133,3 +133,36 @@ def test_dense_entries_on_device_tensors_and_bad_arguments(gpu):
         batch.solve_dense_batch(a[:, :, :9], a[:, :, :8], a[:, :, :9], np.zeros((2, 5, 2)), np.ones((2, 5, 2)), np.ones(4))
     with pytest.raises(ValueError):
         batch.solve_dense_batch(a[:, :, :9], a[:, :, :9], a[:, :, :9], np.zeros((2, 5, 2)), np.ones((2, 5, 2)), np.ones(3))
+
+
+def test_varying_velocity_limits_with_a_constant_function_give_the_fused_path(gpu, oracle):
+    """JointVelocityConstraintVarying is evaluated on the host (a Python callback per gridpoint) and sends the problem to
+    the dense-row entries.  With a constant function it states the fused problem: same bounds (the fp32 rounding of the
+    reference's velocity bound reproduced on the host as on the device), same K / sd / u through two unrelated paths --
+    host rows + full iteration vs rows regenerated on the GPU + certificates.  With a varying function: the oracle."""
+    rng = np.random.default_rng(11)
+    knots, grid = np.linspace(0, 1, 5), np.linspace(0, 1, 81)
+    for d in (2, 5, 7):
+        way = rng.standard_normal((5, d))
+        vlim = np.stack([-2 - 3 * rng.random(d), 2 + 3 * rng.random(d)], axis=1)   # tight: the velocity bound is active
+        alim = np.stack([-10 - 2 * rng.random(d), 10 + 2 * rng.random(d)], axis=1)
+        path = ta.SplineInterpolator(knots, way)
+        acc = ta.constraint.JointAccelerationConstraint(alim)
+        fused = ta.algorithm.TOPPRA([ta.constraint.JointVelocityConstraint(vlim), acc], path, gridpoints=grid)
+        dense = ta.algorithm.TOPPRA([ta.constraint.JointVelocityConstraintVarying(lambda s: vlim), acc], path, gridpoints=grid)
+        assert isinstance(dense.solver_wrapper, hipDenseSeidelWrapper) and not isinstance(fused.solver_wrapper, hipDenseSeidelWrapper)
+        want, got = fused.compute_parameterization(0, 0, return_data=True), dense.compute_parameterization(0, 0, return_data=True)
+        for k, name in ((0, "u"), (1, "sd"), (3, "K")):
+            assert_same(got[k], want[k], "%s (d = %d)" % (name, d))
+        assert_same(dense.compute_feasible_sets(), ta.algorithm.TOPPRA([ta.constraint.JointVelocityConstraint(vlim), acc], path,
+                                                                      gridpoints=grid).compute_feasible_sets(), "X")
+        wavy = ta.algorithm.TOPPRA([ta.constraint.JointVelocityConstraintVarying(lambda s: vlim * (1 + 0.5 * np.sin(9 * s))), acc], path,
+                                   gridpoints=grid)
+        sdd, sd, _, K = wavy.compute_parameterization(0, 0, return_data=True)
+        rows = wavy.solver_wrapper._rows
+        w = oracle.DenseWrapper(*[r[0] for r in rows[:5]], rows[5])
+        st, osdd, osd, oxs, oK = w.compute_parameterization(0.0, 0.0)
+        assert st == 0
+        assert_same(K, oK, "K (varying)")
+        assert_same(sd, osd, "sd (varying)")
+        assert_same(sdd, osdd, "u (varying)")

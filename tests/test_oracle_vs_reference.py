@@ -165,3 +165,50 @@ def test_host_glue_matches_reference(reference):
             sd[5:8] = 0  # a standing stretch (the 5 s rule)
         a, b = ta.ParametrizeSpline(p1, g1, sd), rp.ParametrizeSpline(p2, g2, sd)
         assert np.array_equal(a.cspl.x, b.cspl.x) and np.array_equal(a.cspl.c, b.cspl.c)
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_general_constraint_lists_match_reference(reference, oracle, scheme):
+    """Constraint lists beyond velocity + acceleration, live: the reference's TOPPRA (seidel) on [varying velocity limits,
+    JointTorqueConstraint, SecondOrderConstraint] against (1) toppra_amd's mirror classes (host numpy through the same
+    callbacks) -- same parameters --, (2) toppra_amd.solverwrapper.dense_rows -- the wrapper's row assembly --, (3) the
+    oracle's DenseWrapper on those rows: K, sd, u, feasible sets bit for bit."""
+    import toppra.algorithm as algo
+    import toppra.constraint as rc
+    import toppra_amd as ta
+    from tests.helpers import torque_model
+    from toppra_amd.solverwrapper import dense_rows
+    rng = np.random.default_rng(40 + scheme)
+    knots, grid = np.linspace(0, 1, 5), np.linspace(0, 1, 41)
+    for trial in range(6):
+        d = int(rng.integers(2, 7))
+        way = rng.standard_normal((5, d))
+        inv_dyn = torque_model(1 + rng.random(d), 0.5 * rng.standard_normal(d), 0.3 * rng.standard_normal(d))
+        taulim = np.stack([-6 - 6 * rng.random(d), 6 + 6 * rng.random(d)], axis=1)
+        fric = 0.1 * rng.random(d)
+        base = np.stack([-10 - 5 * rng.random(d), 10 + 5 * rng.random(d)], axis=1)
+        vfun = lambda s: base * (1 + 0.4 * np.sin(5 * s))  # noqa: E731
+        rpath, mpath = reference.SplineInterpolator(knots, way), ta.SplineInterpolator(knots, way)
+        lists = []
+        for mod in (rc, ta.constraint):
+            DT = mod.DiscretizationType(scheme)
+            lists.append([mod.JointVelocityConstraintVarying(vfun), mod.JointTorqueConstraint(inv_dyn, taulim, fric, discretization_scheme=DT),
+                          mod.SecondOrderConstraint.joint_torque_constraint(inv_dyn, 1.3 * taulim, fric, discretization_scheme=DT)])
+        rrows, mrows = dense_rows(lists[0], rpath, grid), dense_rows(lists[1], mpath, grid)
+        for k in ("a", "b", "c", "low", "high", "deltas"):
+            assert_same(mrows[k], rrows[k], "rows %s (mirror classes vs the reference's)" % k)
+        sd0, sd1 = (0.0, 0.0) if trial % 2 else (0.1, 0.05)
+        inst = algo.TOPPRA(lists[0], rpath, gridpoints=grid, solver_wrapper="seidel")
+        sdd, sdv, _, K = inst.compute_parameterization(sd0, sd1, return_data=True)
+        X = algo.TOPPRA(lists[0], rpath, gridpoints=grid, solver_wrapper="seidel").compute_feasible_sets()
+        w = oracle.DenseWrapper(mrows["a"], mrows["b"], mrows["c"], mrows["low"], mrows["high"], mrows["deltas"])
+        st, osdd, osd, oxs, oK = w.compute_parameterization(sd0, sd1)
+        assert_same(oK, K, "K")
+        if sdv is None:
+            assert st == 1
+        else:
+            assert st == 0
+            assert_same(osd, sdv, "sd")
+            assert_same(osdd, sdd, "u")
+        w2 = oracle.DenseWrapper(mrows["a"], mrows["b"], mrows["c"], mrows["low"], mrows["high"], mrows["deltas"])
+        assert_same(w2.compute_feasible_sets(), X, "X")

@@ -33,6 +33,7 @@ timeout 600 python tools/gpu_wave_check.py > gpurun_out/wave_check.log 2>&1; tai
 timeout 600 python tools/gpu_sliver_hunt.py > gpurun_out/sliver_hunt.log 2>&1; tail -3 gpurun_out/sliver_hunt.log
 timeout 300 python tools/gpu_mode_times.py > gpurun_out/mode_times.log 2>&1; cat gpurun_out/mode_times.log
 timeout 300 python tools/gpu_param_pcr_check.py > gpurun_out/param_pcr_check.log 2>&1; tail -4 gpurun_out/param_pcr_check.log
+timeout 300 python tools/gpu_dense_check.py > gpurun_out/dense_check.log 2>&1; tail -5 gpurun_out/dense_check.log
 bash tools/gpu_profile_secondary.sh all > gpurun_out/sec_profile.log 2>&1; tail -3 gpurun_out/sec_profile.log
 if [ -f build_dbg/libtoppra_wtim.so ]; then
   (TOPPRA_HIP_LIB=build_dbg/libtoppra_wtim.so timeout 120 python tools/gpu_wave_phases.py timing 4096 7 200; TOPPRA_HIP_LIB=build_dbg/libtoppra_wtim.so timeout 120 python tools/gpu_wave_phases.py timing 1 7 100) > gpurun_out/wave_phases.log 2>&1; tail -4 gpurun_out/wave_phases.log

@@ -148,6 +148,41 @@ class JointAccelerationConstraint(LinearConstraint):
         return a, b, np.zeros_like(a), F, np.concatenate([g1, g1]), None, None
 
 
+class JointVelocityConstraintVarying(LinearConstraint):
+    """Joint velocity limits that vary along the path: ``vlim_func(s) -> [dof, 2]`` (linear_joint_velocity.py:55-87).
+    Only ``xbound`` is produced.  Evaluated on the host (a Python callback per gridpoint, as in the reference) with the
+    reference's arithmetic: the running bounds sdmin / sdmax are C floats (``_CythonUtils.pyx:60-101`` -- every min / max
+    is rounded to fp32 on assignment, the upper bound is squared in fp32), the quotients are doubles.  Lists holding it
+    run on the dense-row entries (hipDenseSeidelWrapper)."""
+
+    def __init__(self, vlim_func):
+        super(JointVelocityConstraintVarying, self).__init__()
+        self.dof = np.shape(vlim_func(0))[0]
+        self.vlim_func = vlim_func
+        self._format_string = "    Varying Velocity limit: \n"
+
+    def compute_constraint_params(self, path, gridpoints, *args, **kwargs):
+        _check_dof(self, path)
+        gridpoints = np.asarray(gridpoints, dtype=float)
+        qs = np.asarray(path(gridpoints, 1), dtype=float)
+        xbound = np.zeros((len(gridpoints), 2))
+        for i, s in enumerate(gridpoints):
+            vlim = np.asarray(self.vlim_func(s), dtype=float)
+            sdmin, sdmax = np.float32(-1e8), np.float32(1e8)  # MAXSD
+            for k in range(self.dof):
+                if qs[i, k] > 0:
+                    hi, lo = vlim[k, 1] / qs[i, k], vlim[k, 0] / qs[i, k]
+                elif qs[i, k] < 0:
+                    hi, lo = vlim[k, 0] / qs[i, k], vlim[k, 1] / qs[i, k]
+                else:
+                    continue
+                sdmax = np.float32(hi if hi < float(sdmax) else float(sdmax))
+                sdmin = np.float32(lo if lo > float(sdmin) else float(sdmin))
+            lower = float(sdmin) if float(sdmin) > 0.0 else 0.0
+            xbound[i] = lower * lower, float(sdmax * sdmax)
+        return None, None, None, None, None, None, xbound
+
+
 def colloc_to_interpolate(a, b, c, F, g, xbound, ubound, gridpoints, identical=False):
     """First-order interpolation form of canonical-linear parameters (linear_constraint.py:84-192): the constraint of
     stage i is imposed at gridpoint i and, through x_{i+1} = x_i + 2 delta_i u_i, at gridpoint i + 1 -- the row blocks
