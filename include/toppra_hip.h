@@ -192,7 +192,7 @@ int tpr_reachable_sets_batch(const tpr_problem *p, const double *sdmin, const do
  * low_arr, high_arr [N+1][2] and deltas [N]; solve_stagewise_optim (:549-697) and the scans of
  * reachability_algorithm.py:131-376 read nothing else.  These entries take exactly those arrays for B trajectories
  * (the host side builds them as the reference does: toppra_amd.solverwrapper.dense_rows) and run every stage LP through
- * the reference's full Seidel iteration with its warm-start state (rows across 8 / 16 lanes per trajectory; nC <= 66).
+ * the reference's full Seidel iteration with its warm-start state (rows across 8 / 16 / 32 lanes per trajectory; nC <= 122).
  * Results are the reference's bits.  flags: TPR_DEVICE_PTRS, TPR_BOUNDARY_SQUARED.                          */
 typedef struct tpr_dense_problem {
     int32_t B, N, nC, flags;

@@ -65,10 +65,10 @@ def test_dense_fixture_through_the_drop_in_classes(gpu, name):
             float(fx["sdmin_c"]), float(fx["sdmax_c"])), fx["Kc"][b], "Kc[%d]" % b)
 
 
-@pytest.mark.parametrize("B,N,nC,seed", [(64, 30, 2, 1), (200, 25, 7, 2), (96, 40, 34, 3), (64, 20, 35, 4), (40, 16, 66, 5), (33, 1, 12, 6)])
+@pytest.mark.parametrize("B,N,nC,seed", [(64, 30, 2, 1), (200, 25, 7, 2), (96, 40, 34, 3), (64, 20, 35, 4), (40, 16, 66, 5), (33, 1, 12, 6), (24, 12, 67, 7), (16, 10, 122, 8)])
 def test_random_dense_problems_vs_oracle(gpu, oracle, B, N, nC, seed):
-    """Random dense rows -- any row count up to the 66 the slot layouts hold (34 / 35: the switch from 8 to 16 lanes per
-    trajectory), rows of mixed orientation, boxes on u, infeasible stages, failing forward scans -- against the oracle's
+    """Random dense rows -- any row count up to the 122 the slot layouts hold (34 / 35 and 66 / 67: the switches from 8 to 16 to 32
+    lanes per trajectory), rows of mixed orientation, boxes on u, infeasible stages, failing forward scans -- against the oracle's
     seidelWrapper on the same arrays: K, sd2, u, return codes, feasible sets, bit for bit."""
     rng = np.random.default_rng(seed)
     ang = rng.uniform(0, 2 * np.pi, size=(B, N + 1, nC))
@@ -126,7 +126,7 @@ def test_dense_entries_on_device_tensors_and_bad_arguments(gpu):
     got = batch.solve_dense_batch(*rows, torch.from_numpy(fx["sd_start"]).to(dev), torch.from_numpy(fx["sd_end"]).to(dev), want_sd=True)
     assert_same(got["sd"].cpu().numpy(), fx["sd"], "sd (device tensors)")
     assert_same(batch.feasible_sets_dense_batch(*rows).cpu().numpy(), fx["X"], "X (device tensors)")
-    a = np.zeros((2, 5, 67))
+    a = np.zeros((2, 5, 123))
     with pytest.raises(ValueError):
         batch.solve_dense_batch(a, a, a, np.zeros((2, 5, 2)), np.ones((2, 5, 2)), np.ones(4))
     with pytest.raises(ValueError):

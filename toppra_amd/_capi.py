@@ -236,8 +236,8 @@ def make_dense_problem(a, b, c, low, high, deltas, sd_start=None, sd_end=None, s
     N = N1 - 1
     if N < 1:
         raise ValueError("dense rows need at least two gridpoints")
-    if not 2 <= nC <= 66:
-        raise ValueError("nC = %d rows per stage (incl. the two x_next rows) is outside 2..66" % nC)
+    if not 2 <= nC <= 122:
+        raise ValueError("nC = %d rows per stage (incl. the two x_next rows) is outside 2..122" % nC)
     b, c = conv("b", b), conv("c", c)
     low, high = conv("low", low), conv("high", high)
     for name, arr, shape in (("b", b, (B, N1, nC)), ("c", c, (B, N1, nC)), ("low", low, (B, N1, 2)), ("high", high, (B, N1, 2))):

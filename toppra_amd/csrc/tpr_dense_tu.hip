@@ -25,7 +25,7 @@ int dense_launch(const tpr::DenseArgs &A, int feasible, hipStream_t stream) {
 }  // namespace
 
 // nC rows per stage (incl. the two x_next rows) -> the smallest row-slot layout that holds them: 2 + 4 D >= nC.
-// 0 = launched, -1 = more rows than the layouts hold (66).
+// 0 = launched, -1 = more rows than the layouts hold (122: the row keys carry the virtual row index in 7 bits).
 extern "C" __attribute__((visibility("hidden"))) int tpr_tu_dense_launch(const tpr::DenseArgs *A, int feasible, hipStream_t stream) {
     const int D = A->nC <= 6 ? 1 : (A->nC - 2 + 3) / 4;
     switch (D) {
@@ -34,6 +34,10 @@ extern "C" __attribute__((visibility("hidden"))) int tpr_tu_dense_launch(const t
         TPR_DENSE_CASE(5, 8); TPR_DENSE_CASE(6, 8); TPR_DENSE_CASE(7, 8); TPR_DENSE_CASE(8, 8);
         TPR_DENSE_CASE(9, 16); TPR_DENSE_CASE(10, 16); TPR_DENSE_CASE(11, 16); TPR_DENSE_CASE(12, 16);
         TPR_DENSE_CASE(13, 16); TPR_DENSE_CASE(14, 16); TPR_DENSE_CASE(15, 16); TPR_DENSE_CASE(16, 16);
+        TPR_DENSE_CASE(17, 32); TPR_DENSE_CASE(18, 32); TPR_DENSE_CASE(19, 32); TPR_DENSE_CASE(20, 32);
+        TPR_DENSE_CASE(21, 32); TPR_DENSE_CASE(22, 32); TPR_DENSE_CASE(23, 32); TPR_DENSE_CASE(24, 32);
+        TPR_DENSE_CASE(25, 32); TPR_DENSE_CASE(26, 32); TPR_DENSE_CASE(27, 32); TPR_DENSE_CASE(28, 32);
+        TPR_DENSE_CASE(29, 32); TPR_DENSE_CASE(30, 32);
 #undef TPR_DENSE_CASE
     }
     return -1;

@@ -946,7 +946,7 @@ int check_dense(const tpr_dense_problem *p) {
     if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
     if (!p) return fail(TPR_E_BADARG, "null dense problem");
     if (p->B < 0 || p->N < 1) return fail(TPR_E_BADARG, "dense problem: B >= 0, N >= 1");
-    if (p->nC < 2 || p->nC > 66) return fail(TPR_E_UNSUPPORTED, "dense problem: 2 <= nC <= 66 rows per stage (incl. the two x_next rows)");
+    if (p->nC < 2 || p->nC > 122) return fail(TPR_E_UNSUPPORTED, "dense problem: 2 <= nC <= 122 rows per stage (incl. the two x_next rows)");
     if (!p->a || !p->b || !p->c || !p->low || !p->high || !p->deltas) return fail(TPR_E_BADARG, "dense problem: a, b, c, low, high, deltas are required");
     return TPR_E_OK;
 }

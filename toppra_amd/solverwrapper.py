@@ -242,8 +242,8 @@ class hipDenseSeidelWrapper(SolverWrapper):
         self.deltas = rows["deltas"]
         self.nC = rows["nC"]
         self.params = rows["params"]
-        if self.nC > 66:
-            raise NotImplementedError("%d constraint rows per stage: the dense-row kernels hold 66" % self.nC)
+        if self.nC > 122:
+            raise NotImplementedError("%d constraint rows per stage: the dense-row kernels hold 122" % self.nC)
         self._rows = tuple(np.ascontiguousarray(rows[k][None]) for k in ("a", "b", "c", "low", "high")) + (self.deltas,)
 
     def controllable_sets(self, sdmin, sdmax):
