@@ -166,3 +166,29 @@ def test_varying_velocity_limits_with_a_constant_function_give_the_fused_path(gp
         assert_same(K, oK, "K (varying)")
         assert_same(sd, osd, "sd (varying)")
         assert_same(sdd, osdd, "u (varying)")
+
+
+def test_dense_wrapper_single_lp_entry(gpu, oracle):
+    """hipDenseSeidelWrapper.solve_stagewise_optim (the reference's per-stage contract, cy_seidel_solverwrapper.pyx:549-697)
+    against the oracle's on the same rows: a backward sweep of 2-D LPs with the warm-start state carried from call to
+    call, absent (NaN) bounds, the last stage, and the 1-variable path of the forward step -- every [u, x] bit for bit."""
+    fx = golden("dense_vel_acc_second_d6_N50")
+    b = int(np.flatnonzero(fx["status"] == 0)[0])
+    path = ta.SplineInterpolator(fx["knots"], fx["way"][b])
+    w = hipDenseSeidelWrapper(dense_constraints(fx, b, ta.constraint), path, fx["grid"], solve_lp1d=1)
+    o = oracle.DenseWrapper(fx["a"][b], fx["b"][b], fx["c"][b], fx["low"][b], fx["high"][b], fx["deltas"], solve_lp1d=1)
+    N = w.get_no_stages()
+    assert w.get_no_vars() == 2 and N == 50 and np.array_equal(w.get_deltas(), fx["deltas"])
+    nan = float("nan")
+    K = fx["K"][b]
+    calls = [(N, [1e-9, -1.0], nan, nan, nan, nan), (N, [-1e-9, 1.0], 0.0, 1e4, nan, nan)]
+    for i in range(N - 1, 30, -1):                      # _one_step: upper then lower bound of the controllable set
+        calls += [(i, [1e-9, -1.0], nan, nan, K[i + 1, 0], K[i + 1, 1]), (i, [-1e-9, 1.0], nan, nan, K[i + 1, 0], K[i + 1, 1])]
+    for i in range(0, 8):                               # the forward step: x_min == x_max -> the 1-variable LP
+        x = float(fx["sd"][b, i]) ** 2
+        calls.append((i, [-2 * fx["deltas"][i], -1.0], x, x, K[i + 1, 0], K[i + 1, 1]))
+    calls.append((3, [0.3, 0.7], 0.1, 0.2, nan, 5.0))    # a generic objective, one-sided x_next bound
+    for i, g, x0, x1, n0, n1 in calls:
+        got = w.solve_stagewise_optim(i, None, np.array(g), x0, x1, n0, n1)
+        want = o.solve_stagewise_optim(i, None, np.array(g), x0, x1, n0, n1)
+        assert_same(np.asarray(got), np.asarray(want), "stage %d g %s" % (i, g))

@@ -245,6 +245,8 @@ class hipDenseSeidelWrapper(SolverWrapper):
         if self.nC > 122:
             raise NotImplementedError("%d constraint rows per stage: the dense-row kernels hold 122" % self.nC)
         self._rows = tuple(np.ascontiguousarray(rows[k][None]) for k in ("a", "b", "c", "low", "high")) + (self.deltas,)
+        self._solve_lp1d = int(solve_lp1d)
+        self._active_up, self._active_down = np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.int32)  # solve_stagewise_optim's state
 
     def controllable_sets(self, sdmin, sdmax):
         return batch.controllable_sets_dense_batch(*self._rows, np.array([sdmin ** 2], dtype=np.float64),
@@ -259,6 +261,49 @@ class hipDenseSeidelWrapper(SolverWrapper):
         res = {k: v[0] for k, v in out.items() if k != "status"}
         res["status"] = int(out["status"][0])
         return res
+
+    # -- single-LP compatibility entry (cy_seidel_solverwrapper.pyx:549-697) on the stage's dense rows: the bounds and the
+    # x_next pair are set up as the reference sets them up, the LP itself runs on the library's LP entries
+    # (tpr_lp1d_batch / tpr_lp2d_batch = cy_solve_lp1d / cy_solve_lp2d), the two warm-start sets persist between calls
+    def solve_stagewise_optim(self, i, H, g, x_min, x_max, x_next_min, x_next_max):
+        assert 0 <= i <= self.N
+        _capi.init()
+        lib = _capi.load()
+        a, b, c = (np.array(r[0, i]) for r in self._rows[:3])
+        low, high = np.array(self._rows[3][0, i]), np.array(self._rows[4][0, i])
+        if not np.isnan(x_min):
+            low[1] = low[1] if low[1] > x_min else x_min
+        if not np.isnan(x_max):
+            high[1] = high[1] if high[1] < x_max else x_max
+        a[:2], b[:2], c[:2] = 0.0, 0.0, -1.0  # absent bounds / the last stage: the disabled row
+        if i < self.N:
+            if not np.isnan(x_next_min):
+                a[0], b[0], c[0] = -2 * self.deltas[i], -1.0, x_next_min
+            if not np.isnan(x_next_max):
+                a[1], b[1], c[1] = 2 * self.deltas[i], 1.0, -x_next_max
+        upper = g[1] > 0
+        res, val, active = np.zeros(1, np.int32), np.zeros(1), np.zeros(2, np.int32)
+        if x_min == x_max and self._solve_lp1d > 0:
+            bx_c = b * x_min + c
+            v = np.array([-g[0], -g[1] * x_min], dtype=np.float64)
+            var, u_low, u_high = np.zeros(1), np.array([low[0]]), np.array([high[0]])  # (named: the call takes raw addresses)
+            _capi.check(lib.tpr_lp1d_batch(1, self.nC, _capi.ptr(v), _capi.ptr(a), _capi.ptr(bx_c), _capi.ptr(u_low),
+                                           _capi.ptr(u_high), _capi.ptr(res), _capi.ptr(val), _capi.ptr(var),
+                                           _capi.ptr(active), None))
+            if res[0] == 0:
+                return np.array([np.nan, np.nan])
+            (self._active_up if upper else self._active_down)[0] = active[0]
+            return np.array([var[0], x_min])
+        warm = self._active_up if upper else self._active_down
+        v = np.array([-g[0], -g[1], 0.0], dtype=np.float64)
+        var = np.zeros(2)
+        _capi.check(lib.tpr_lp2d_batch(1, self.nC, _capi.ptr(v), _capi.ptr(a), _capi.ptr(b), _capi.ptr(c), _capi.ptr(low),
+                                       _capi.ptr(high), _capi.ptr(warm), _capi.ptr(res), _capi.ptr(val), _capi.ptr(var),
+                                       _capi.ptr(active), None))
+        if res[0] == 0:
+            return np.array([np.nan, np.nan])
+        warm[:] = active
+        return var
 
     def reachable_sets(self, sdmin, sdmax):
         raise NotImplementedError("reachable sets are implemented for velocity + acceleration constraints (hipSeidelWrapper)")
