@@ -65,7 +65,8 @@ def test_dense_fixture_through_the_drop_in_classes(gpu, name):
             float(fx["sdmin_c"]), float(fx["sdmax_c"])), fx["Kc"][b], "Kc[%d]" % b)
 
 
-@pytest.mark.parametrize("B,N,nC,seed", [(64, 30, 2, 1), (200, 25, 7, 2), (96, 40, 34, 3), (64, 20, 35, 4), (40, 16, 66, 5), (33, 1, 12, 6), (24, 12, 67, 7), (16, 10, 122, 8)])
+@pytest.mark.parametrize("B,N,nC,seed", [(64, 30, 2, 1), (200, 25, 7, 2), (96, 40, 34, 3), (64, 20, 35, 4), (40, 16, 66, 5), (33, 1, 12, 6), (24, 12, 67, 7), (16, 10, 122, 8),
+                                        (3000, 40, 30, 9), (1500, 30, 50, 10)])
 def test_random_dense_problems_vs_oracle(gpu, oracle, B, N, nC, seed):
     """Random dense rows -- any row count up to the 122 the slot layouts hold (34 / 35 and 66 / 67: the switches from 8 to 16 to 32
     lanes per trajectory), rows of mixed orientation, boxes on u, infeasible stages, failing forward scans -- against the oracle's
