@@ -205,6 +205,10 @@ typedef struct tpr_dense_problem {
 /* compute_parameterization (reachability_algorithm.py:240-376): outputs and status codes as tpr_solve_batch (r->K is
  * required; sd2 / sd / u / status may be NULL).                                                            */
 int tpr_solve_dense_batch(const tpr_dense_problem *p, const tpr_result *r, void *stream);
+/* TOPPRAsd.compute_parameterization (desired_duration_algorithm.py:42-234) on dense rows: as
+ * tpr_solve_desired_duration_batch (desired [B] seconds, atol, alpha [B] may be NULL).                       */
+int tpr_solve_desired_duration_dense_batch(const tpr_dense_problem *p, const double *desired, double atol,
+                                           const tpr_result *r, double *alpha, void *stream);
 /* compute_controllable_sets(sdmin, sdmax) (:166-238): K [B][N+1][2]; p->sd_start / sd_end are not used.       */
 int tpr_controllable_sets_dense_batch(const tpr_dense_problem *p, const double *sdmin, const double *sdmax, double *K,
                                       void *stream);

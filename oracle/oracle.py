@@ -271,6 +271,28 @@ def solve_dense_batch(a, b, c, low, high, deltas, sd_start=None, sd_end=None, wa
     return out
 
 
+def solve_dense_batch_sd(a, b, c, low, high, deltas, desired_duration, sd_start=None, sd_end=None, atol=1e-5):
+    """TOPPRAsd on dense rows for B trajectories (the checker of tpr_solve_desired_duration_dense_batch):
+    dict(sd2, sd, u, K, status, alpha)."""
+    a, b, c, low, high = (_f64(x) for x in (a, b, c, low, high))
+    B, N1, _ = a.shape
+    N = N1 - 1
+    deltas = np.broadcast_to(_f64(deltas), (B, N))
+    sd0 = np.broadcast_to(np.zeros(1) if sd_start is None else _f64(sd_start), (B,))
+    sd1 = np.broadcast_to(np.zeros(1) if sd_end is None else _f64(sd_end), (B,))
+    desired = np.broadcast_to(_f64(desired_duration), (B,))
+    out = {"sd2": np.zeros((B, N + 1)), "sd": np.zeros((B, N + 1)), "u": np.zeros((B, N)), "K": np.zeros((B, N + 1, 2)),
+           "status": np.zeros(B, dtype=np.int32), "alpha": np.zeros(B)}
+    for i in range(B):
+        w = DenseWrapper(a[i], b[i], c[i], low[i], high[i], np.ascontiguousarray(deltas[i]))
+        alpha = C.c_double(float("nan"))
+        sdd, sd, xs, K = np.zeros(N), np.zeros(N + 1), np.zeros(N + 1), np.zeros((N + 1, 2))
+        out["status"][i] = lib().orc_compute_parameterization_sd(w._h, float(sd0[i]), float(sd1[i]), float(desired[i]), float(atol),
+                                                                 _dp(sdd), _dp(sd), _dp(xs), _dp(K), C.byref(alpha))
+        out["u"][i], out["sd"][i], out["sd2"][i], out["K"][i], out["alpha"][i] = sdd, sd, xs, K, alpha.value
+    return out
+
+
 def robust_solve_batch(coef, breaks, grid, vlim, alim, ellipsoid, sd_start=None, sd_end=None,
                        flags=DEFAULT_FLAGS, want_X=True, nthreads=1):
     """Robust (conic) TOPP-RA, PARITY UNPINNED against ECOS, cross-checked at 1e-7 against robust_independent.py (see seidel_oracle.c): dict(sd2, u, K, X, status)."""

@@ -193,3 +193,48 @@ def test_dense_wrapper_single_lp_entry(gpu, oracle):
         got = w.solve_stagewise_optim(i, None, np.array(g), x0, x1, n0, n1)
         want = o.solve_stagewise_optim(i, None, np.array(g), x0, x1, n0, n1)
         assert_same(np.asarray(got), np.asarray(want), "stage %d g %s" % (i, g))
+
+
+@pytest.mark.parametrize("name", dense_fixtures())
+def test_dense_fixture_desired_duration(gpu, name):
+    """TOPPRAsd of the REFERENCE on torque / second-order constraint lists: tpr_solve_desired_duration_dense_batch on the
+    fixture's rows, and toppra_amd.algorithm.TOPPRAsd on toppra_amd's own constraint classes -- K, sd, u, return codes bit
+    for bit (desired durations below the fastest, in range -- the bisection --, above the slowest; uncontrollable starts)."""
+    fx = golden(name)
+    got = batch.solve_desired_duration_dense_batch(*_rows(fx), fx["sd_desired"], fx["sd_start"], fx["sd_end"])
+    assert np.array_equal(got["status"], fx["sd_status"])
+    assert_same(got["K"], fx["sd_K"], "K")
+    assert_same(got["sd"], fx["sd_sd"], "sd")
+    assert_same(got["u"], fx["sd_u"], "u")
+    ok = fx["sd_status"] == 0
+    assert np.all((got["alpha"][ok] >= 0) & (got["alpha"][ok] <= 1)) and np.any((got["alpha"][ok] > 0) & (got["alpha"][ok] < 1))
+    for b in range(fx["a"].shape[0]):
+        inst = ta.algorithm.TOPPRAsd(dense_constraints(fx, b, ta.constraint), ta.SplineInterpolator(fx["knots"], fx["way"][b]),
+                                     gridpoints=fx["grid"])
+        inst.set_desired_duration(float(fx["sd_desired"][b]))
+        sdd, sd, _, K = inst.compute_parameterization(fx["sd_start"][b], fx["sd_end"][b], return_data=True)
+        assert_same(K, fx["sd_K"][b], "K[%d]" % b)
+        if fx["sd_status"][b] != 1:  # (2 = a NaN in the blended profile: arrays with NaNs, as the reference returns them)
+            assert_same(sd, fx["sd_sd"][b], "sd[%d]" % b)
+            assert_same(sdd, fx["sd_u"][b], "u[%d]" % b)
+        else:
+            assert sd is None
+
+
+def test_dense_desired_duration_vs_the_fused_path(gpu):
+    """TOPPRAsd on the standard problem's own rows (dense) against the fused TOPPRAsd kernels: every output bit, blend
+    factors included, on a batch with desired durations below, inside and far above the achievable range and boundary velocities."""
+    B, d, N = 600, 6, 80
+    rng = np.random.default_rng(4)
+    data = batch.make_synthetic_batch(B, d, N, seed=9)
+    args = (data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    sd0 = 0.2 * rng.random(B) * (rng.random(B) < 0.4)
+    desired = np.choose(np.arange(B) % 4, [0.3, 1.5, 3.0, 1e5]) * (1 + 0.2 * rng.random(B))
+    ref = batch.solve_desired_duration_batch(*args, desired, sd0, None)
+    rows = batch.constraint_params_batch(*args)
+    got = batch.solve_desired_duration_dense_batch(rows["a"], rows["b"], rows["c"], rows["low"], rows["high"], np.diff(data["grid"]),
+                                                   desired, sd0, None)
+    for k in ("K", "sd2", "sd", "u", "alpha"):
+        assert_same(got[k], ref[k], k)
+    assert np.array_equal(got["status"], ref["status"])
+    assert np.any((ref["alpha"] > 0) & (ref["alpha"] < 1)) and np.any(ref["alpha"] == 1.0)

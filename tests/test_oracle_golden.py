@@ -149,6 +149,19 @@ def test_dense_fixture(oracle, name):
         assert_same(w.compute_controllable_sets(float(fx["sdmin_c"]), float(fx["sdmax_c"])), fx["Kc"][b], "Kc[%d]" % b)
 
 
+@pytest.mark.parametrize("name", dense_fixtures())
+def test_dense_fixture_desired_duration(oracle, name):
+    """TOPPRAsd of the REFERENCE on the torque / second-order constraint lists (unachievably short, in-range and
+    unachievably long desired durations, uncontrollable starts): the oracle on the fixture's dense rows, bit for bit."""
+    fx = golden(name)
+    got = oracle.solve_dense_batch_sd(fx["a"], fx["b"], fx["c"], fx["low"], fx["high"], fx["deltas"], fx["sd_desired"],
+                                      fx["sd_start"], fx["sd_end"])
+    assert np.array_equal(got["status"], fx["sd_status"])
+    assert_same(got["K"], fx["sd_K"], "K")
+    assert_same(got["sd"], fx["sd_sd"], "sd")
+    assert_same(got["u"], fx["sd_u"], "u")
+
+
 def test_dense_rows_from_the_mirror_constraint_classes():
     """toppra_amd's own SecondOrderConstraint / JointTorqueConstraint (host numpy through the user's inverse dynamics, as in
     the reference) + dense_rows against the rows the REFERENCE's constraint objects gave (fixtures without a velocity /

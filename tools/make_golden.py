@@ -477,7 +477,19 @@ def dense_fixture(name, B, d, N, seed, kinds, scheme, sd_mode="zero"):
         rows = dense_rows(cons, path, grid)
         for k in ("a", "b", "c", "low", "high"):
             out[k].append(rows[k])
+        # TOPPRAsd on the same constraint list: unachievably short, in-range and unachievably long desired durations
+        fast = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_trajectory(sd0[b], sd1[b])
+        desired = float((fast.duration if fast is not None else 1.0) * [0.5, 1.3, 2.5, 1e4][b % 4])
+        inst_sd = algo.TOPPRAsd(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        inst_sd.set_desired_duration(desired)
+        sdd2, sd2v, _, K2 = inst_sd.compute_parameterization(sd0[b], sd1[b], return_data=True)
+        if sd2v is None:
+            sd2v, sdd2 = np.full(N + 1, np.nan), np.full(N, np.nan)
+        for k, val in (("sd_desired", desired), ("sd_K", K2), ("sd_sd", sd2v), ("sd_u", sdd2),
+                       ("sd_status", STATUS[inst_sd.problem_data.return_code])):
+            out.setdefault(k, []).append(val)
     rec = {k: np.stack(v) for k, v in out.items()}
+    rec["sd_status"] = rec["sd_status"].astype(np.int32)
     rec["status"] = rec["status"].astype(np.int32)
     rec.update(deltas=np.diff(grid), grid=grid, knots=knots, way=way, mass=mass, grav=grav, cori=cori, taumax=taumax, fric=fric,
                vmax=vmax, amax=amax, sd_start=sd0, sd_end=sd1, scheme=np.array(scheme), kinds=np.array(",".join(kinds)),

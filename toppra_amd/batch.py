@@ -184,6 +184,22 @@ def solve_dense_batch(a, b, c, low, high, deltas, sd_start=None, sd_end=None, wa
     return out
 
 
+def solve_desired_duration_dense_batch(a, b, c, low, high, deltas, desired_duration, sd_start=None, sd_end=None, atol=1e-5):
+    """TOPPRAsd.compute_parameterization on dense rows (see :func:`solve_dense_batch`, :func:`solve_desired_duration_batch`):
+    dict(sd2, sd, u, K, status, alpha)."""
+    _prepare(a)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, sd_start, sd_end)
+    B, N = p.B, p.N
+    desired = _capi.per_traj_vector("desired_duration", desired_duration, B, a)
+    out = {"sd2": _empty(a, (B, N + 1)), "sd": _empty(a, (B, N + 1)), "u": _empty(a, (B, N)),
+           "K": _empty(a, (B, N + 1, 2)), "status": _empty(a, (B,), "i32"), "alpha": _empty(a, (B,))}
+    r = _capi.tpr_result(sd2=_capi.ptr(out["sd2"]), sd=_capi.ptr(out["sd"]), u=_capi.ptr(out["u"]),
+                         K=_capi.ptr(out["K"]), status=_capi.ptr(out["status"]))
+    _capi.check(_capi.load().tpr_solve_desired_duration_dense_batch(C.byref(p), _capi.ptr(desired), float(atol), C.byref(r),
+                                                                    _capi.ptr(out["alpha"]), _stream_ptr(a)))
+    return out
+
+
 def controllable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, squared=False):
     """compute_controllable_sets(sdmin, sdmax) on dense rows (see :func:`solve_dense_batch`) -> K [B, N+1, 2]."""
     _prepare(a)

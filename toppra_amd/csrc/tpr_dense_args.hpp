@@ -12,5 +12,7 @@ struct DenseArgs {
     int32_t *status;
     double *X;                   // feasible sets [B][N+1][2] (mode 2)
     int backward_only;
+    // TOPPRAsd: the fastest / slowest forward profiles x [B][N+1], u [B][N] (dense_sd_forward_kernel reads K and status)
+    double *sd_xf, *sd_uf, *sd_xl, *sd_ul;
 };
 }  // namespace tpr

@@ -11,14 +11,15 @@
 
 namespace {
 template <int D, int L>
-int dense_launch(const tpr::DenseArgs &A, int feasible, hipStream_t stream) {
+int dense_launch(const tpr::DenseArgs &A, int feasible /* 0 solve, 1 feasible sets, 2 TOPPRAsd forward scans */, hipStream_t stream) {
     using C = tpr::GroupCfg<D, L>;
     int threads = 256;
     while (threads > 64 && (long long)A.B * L / threads < 4 * 256) threads /= 2;  // small batches: more, smaller blocks
     const int groups = threads / L;
     const size_t lds = (size_t)groups * C::kRowBuf * sizeof(double);
     const dim3 grid((A.B + groups - 1) / groups), block(threads);
-    if (feasible) hipLaunchKernelGGL((tpr::dense_feasible_kernel<D, L>), grid, block, lds, stream, A);
+    if (feasible == 1) hipLaunchKernelGGL((tpr::dense_feasible_kernel<D, L>), grid, block, lds, stream, A);
+    else if (feasible == 2) hipLaunchKernelGGL((tpr::dense_sd_forward_kernel<D, L>), grid, block, lds, stream, A);
     else hipLaunchKernelGGL((tpr::dense_solve_kernel<D, L>), grid, block, lds, stream, A);
     return 0;
 }

@@ -979,6 +979,58 @@ int tpr_solve_dense_batch(const tpr_dense_problem *p, const tpr_result *r, void 
     return TPR_E_OK;
 }
 
+int tpr_solve_desired_duration_dense_batch(const tpr_dense_problem *p, const double *desired, double atol, const tpr_result *r,
+                                           double *alpha, void *stream_) {
+    if (int rc = check_dense(p)) return rc;
+    if (!r || !r->K || !desired) return fail(TPR_E_BADARG, "result.K and desired are required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->a));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::DenseArgs A = stage_dense(p, S);
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    const double *ddes = S.in(desired, B);
+    A.sd_start = S.in(p->sd_start, B); A.sd_end = S.in(p->sd_end, B);
+    double *dsd2 = S.out(r->sd2, B * (N + 1)), *dsd = S.out(r->sd, B * (N + 1)), *du = S.out(r->u, B * N);
+    A.K = S.out(r->K, B * (N + 1) * 2); A.status = S.out(r->status, B);
+    double *dalpha = S.out(alpha, B);
+    // workspace: fastest / slowest profiles, the bisection's worklist, a status / alpha array when the caller wants none
+    double *ws = nullptr;
+    int32_t *wstatus = nullptr, *wlist = nullptr;
+    const size_t per = 2 * (N + 1) + 2 * N;
+    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * (per + (dalpha ? 0 : 1)) * sizeof(double) + 8, stream);
+    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&wlist), (B + 2) * sizeof(int32_t), stream);
+    if (S.err == hipSuccess && !A.status) {
+        S.err = hipMallocAsync(reinterpret_cast<void **>(&wstatus), B * sizeof(int32_t) + 4, stream);
+        A.status = wstatus;
+    }
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    S.owned.push_back(ws);
+    S.owned.push_back(wlist);
+    if (wstatus) S.owned.push_back(wstatus);
+    if (!dalpha) dalpha = ws + B * per;
+    if (A.B > 0) {
+        A.sd_xf = ws; A.sd_uf = ws + B * (N + 1); A.sd_xl = ws + B * (2 * N + 1); A.sd_ul = ws + B * (3 * N + 2);
+        // backward scan -> K and the controllability verdict, the two forward scans, then durations / bisection / blend
+        A.backward_only = 1;
+        if (tpr_tu_dense_launch(&A, 0, stream) != 0 || tpr_tu_dense_launch(&A, 2, stream) != 0)
+            return fail(TPR_E_UNSUPPORTED, "dense TOPPRAsd: no kernel for this row count");
+        tpr::SdBlendArgs G{A.B, A.N, A.flags, atol, nullptr, ddes, A.sd_xf, A.sd_uf, A.sd_xl, A.sd_ul, A.status,
+                           dsd2, dsd, du, dalpha, A.status, A.deltas};
+        const size_t finish_lds = 5 * (N + 1) * sizeof(double);
+        if (finish_lds <= kMaxDynamicLds) {
+            hipLaunchKernelGGL(tpr::sd_finish_kernel, dim3(A.B), dim3(64), finish_lds, stream, G);
+        } else {
+            HIP_TRY(hipMemsetAsync(wlist + B, 0, sizeof(int32_t), stream));
+            hipLaunchKernelGGL(tpr::sd_decide_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, G, wlist, wlist + B);
+            hipLaunchKernelGGL(tpr::sd_bisect_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, G, wlist, wlist + B);
+            hipLaunchKernelGGL(tpr::sd_blend_kernel, dim3(A.B), dim3(64), 0, stream, G);
+        }
+    }
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
 int tpr_controllable_sets_dense_batch(const tpr_dense_problem *p, const double *sdmin, const double *sdmax, double *K,
                                       void *stream_) {
     if (int rc = check_dense(p)) return rc;

@@ -226,7 +226,8 @@ class hipDenseSeidelWrapper(SolverWrapper):
     reference's own constraint objects, hand-written ones): the constraints' parameters are evaluated on the host, as in
     the reference, flattened by :func:`dense_rows`, and the passes run on the dense-row entries of the library
     (tpr_*_dense_batch: rows across lanes, the reference's full Seidel iteration).  Every pass starts from a fresh
-    object's warm-start state (compute_trajectory on a new instance -- the usual flow -- returns the reference's bits)."""
+    object's warm-start state (compute_trajectory on a new instance -- the usual flow -- returns the reference's bits).
+    TOPPRAsd runs here too; reachable sets exist for velocity + acceleration problems only."""
 
     def __init__(self, constraint_list, path, path_discretization, solve_lp1d=1):
         self.constraints = constraint_list
@@ -309,7 +310,9 @@ class hipDenseSeidelWrapper(SolverWrapper):
         raise NotImplementedError("reachable sets are implemented for velocity + acceleration constraints (hipSeidelWrapper)")
 
     def parameterization_sd(self, sd_start, sd_end, desired_duration, atol=1e-5):
-        raise NotImplementedError("TOPPRAsd is implemented for velocity + acceleration constraints (hipSeidelWrapper)")
+        out = batch.solve_desired_duration_dense_batch(*self._rows, desired_duration, np.array([sd_start], dtype=np.float64),
+                                                       np.array([sd_end], dtype=np.float64), atol)
+        return {k: v[0] for k, v in out.items()}
 
 
 class hipRobustWrapper(SolverWrapper):
