@@ -214,6 +214,10 @@ int tpr_controllable_sets_dense_batch(const tpr_dense_problem *p, const double *
                                       void *stream);
 /* compute_feasible_sets (:131-164): X [B][N+1][2].                                                          */
 int tpr_feasible_sets_dense_batch(const tpr_dense_problem *p, double *X, void *stream);
+/* compute_reachable_sets(sdmin, sdmax) (:378-431): as tpr_reachable_sets_batch (L [B][N+1][2]; X may be NULL); one
+ * trajectory per lane, the reference's per-stage calls with their stateful warm start.                     */
+int tpr_reachable_sets_dense_batch(const tpr_dense_problem *p, const double *sdmin, const double *sdmax, double *L, double *X,
+                                   void *stream);
 
 /* Replaces Constraint.compute_constraint_params + the dense row build of seidelWrapper.__init__
  * (linear_joint_velocity.py:43-53, linear_joint_acceleration.py:63-104,

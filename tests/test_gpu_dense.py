@@ -33,6 +33,12 @@ def test_dense_fixture(gpu, name):
     B = fx["a"].shape[0]
     Kc = batch.controllable_sets_dense_batch(*_rows(fx), np.full(B, float(fx["sdmin_c"])), np.full(B, float(fx["sdmax_c"])))
     assert_same(Kc, fx["Kc"], "controllable sets")
+    # reachable sets from an interval and from a point (sdmin == sdmax: the first stage takes the 1-variable path, whose
+    # active index seeds the later warm starts)
+    L, X = batch.reachable_sets_dense_batch(*_rows(fx), np.zeros(B), np.full(B, 0.3), want_X=True)
+    assert_same(L, fx["L"], "reachable sets")
+    assert_same(X, fx["X"], "X of the reachable-set pass")
+    assert_same(batch.reachable_sets_dense_batch(*_rows(fx), np.full(B, 0.1), np.full(B, 0.1)), fx["L_point"], "reachable sets from a point")
 
 
 @pytest.mark.parametrize("name", dense_fixtures())
@@ -63,6 +69,7 @@ def test_dense_fixture_through_the_drop_in_classes(gpu, name):
         assert_same(ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"]).compute_feasible_sets(), fx["X"][b], "X[%d]" % b)
         assert_same(ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"]).compute_controllable_sets(
             float(fx["sdmin_c"]), float(fx["sdmax_c"])), fx["Kc"][b], "Kc[%d]" % b)
+        assert_same(ta.algorithm.TOPPRA(cons, path, gridpoints=fx["grid"]).compute_reachable_sets(0.0, 0.3), fx["L"][b], "L[%d]" % b)
 
 
 @pytest.mark.parametrize("B,N,nC,seed", [(64, 30, 2, 1), (200, 25, 7, 2), (96, 40, 34, 3), (64, 20, 35, 4), (40, 16, 66, 5), (33, 1, 12, 6), (24, 12, 67, 7), (16, 10, 122, 8),

@@ -147,6 +147,9 @@ def test_dense_fixture(oracle, name):
     for b in range(fx["a"].shape[0]):
         w = oracle.DenseWrapper(fx["a"][b], fx["b"][b], fx["c"][b], fx["low"][b], fx["high"][b], fx["deltas"])
         assert_same(w.compute_controllable_sets(float(fx["sdmin_c"]), float(fx["sdmax_c"])), fx["Kc"][b], "Kc[%d]" % b)
+        for key, lo, hi in (("L", 0.0, 0.3), ("L_point", 0.1, 0.1)):  # reachable sets (a point start: the 1-variable path first)
+            w = oracle.DenseWrapper(fx["a"][b], fx["b"][b], fx["c"][b], fx["low"][b], fx["high"][b], fx["deltas"])
+            assert_same(w.compute_reachable_sets(lo, hi)[0], fx[key][b], "%s[%d]" % (key, b))
 
 
 @pytest.mark.parametrize("name", dense_fixtures())

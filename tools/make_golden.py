@@ -474,6 +474,8 @@ def dense_fixture(name, B, d, N, seed, kinds, scheme, sd_mode="zero"):
         out["K"].append(K); out["sd"].append(sd); out["u"].append(sdd); out["status"].append(st)
         out["X"].append(algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_feasible_sets())
         out["Kc"].append(algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_controllable_sets(0.05, 0.4))
+        out.setdefault("L", []).append(algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_reachable_sets(0.0, 0.3))
+        out.setdefault("L_point", []).append(algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel").compute_reachable_sets(0.1, 0.1))
         rows = dense_rows(cons, path, grid)
         for k in ("a", "b", "c", "low", "high"):
             out[k].append(rows[k])

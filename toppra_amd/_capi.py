@@ -61,7 +61,7 @@ EXPORTS = (
     "tpr_spline_fit_batch", "tpr_const_accel_times_batch", "tpr_const_accel_eval_batch",
     "tpr_solve_desired_duration_batch", "tpr_robust_solve_batch", "tpr_param_spline_batch", "tpr_ppoly_eval_batch",
     "tpr_reachable_sets_batch", "tpr_solve_dense_batch", "tpr_controllable_sets_dense_batch", "tpr_feasible_sets_dense_batch",
-    "tpr_solve_desired_duration_dense_batch",
+    "tpr_solve_desired_duration_dense_batch", "tpr_reachable_sets_dense_batch",
 )
 
 _lib = None
@@ -135,6 +135,8 @@ def load():
         L.tpr_solve_dense_batch.argtypes = [DP, R, V]
         L.tpr_solve_desired_duration_dense_batch.restype = C.c_int
         L.tpr_solve_desired_duration_dense_batch.argtypes = [DP, V, C.c_double, R, V, V]
+        L.tpr_reachable_sets_dense_batch.restype = C.c_int
+        L.tpr_reachable_sets_dense_batch.argtypes = [DP, V, V, V, V, V]
         L.tpr_controllable_sets_dense_batch.restype = C.c_int
         L.tpr_controllable_sets_dense_batch.argtypes = [DP, V, V, V, V]
         L.tpr_feasible_sets_dense_batch.restype = C.c_int

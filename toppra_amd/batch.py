@@ -212,6 +212,20 @@ def controllable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, squa
     return K
 
 
+def reachable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, want_X=False):
+    """compute_reachable_sets(sdmin, sdmax) on dense rows (see :func:`solve_dense_batch`) -> L [B, N+1, 2] (and the feasible
+    sets X it computes on the way with ``want_X``)."""
+    _prepare(a)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas)
+    sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, a)
+    sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, a)
+    L = _empty(a, (p.B, p.N + 1, 2))
+    X = _empty(a, (p.B, p.N + 1, 2)) if want_X else None
+    _capi.check(_capi.load().tpr_reachable_sets_dense_batch(C.byref(p), _capi.ptr(sdmin), _capi.ptr(sdmax), _capi.ptr(L),
+                                                            _capi.ptr(X), _stream_ptr(a)))
+    return (L, X) if want_X else L
+
+
 def feasible_sets_dense_batch(a, b, c, low, high, deltas):
     """compute_feasible_sets on dense rows (see :func:`solve_dense_batch`) -> X [B, N+1, 2]."""
     _prepare(a)

@@ -941,6 +941,62 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
 }
 
 // ---- dense rows (any canonical-linear constraint list): tpr_dense.hip.inc ----------------------------------------
+namespace tpr {
+// compute_reachable_sets (reachability_algorithm.py:378-431) on dense rows: lane_reachable_kernel (tpr_lane.hip.inc: one
+// trajectory per lane, the reference's solve_stagewise_optim with its stateful warm start, the deltas[i - 1] quirk of
+// _one_step_forward) with the stage rows copied from the arrays instead of generated.
+static __global__ void __launch_bounds__(64) lane_dense_reachable_kernel(DenseArgs A, const double *sdmin, const double *sdmax,
+                                                                  double *L, double *X) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.B) return;
+    const int N = A.N, nC = A.nC;
+    const double *ga = A.a + (size_t)b * (N + 1) * nC, *gb = A.b + (size_t)b * (N + 1) * nC, *gc = A.c + (size_t)b * (N + 1) * nC;
+    const double *glow = A.low + (size_t)b * 2 * (N + 1), *ghigh = A.high + (size_t)b * 2 * (N + 1);
+    const double *deltas = A.deltas + (size_t)b * N;
+    StageRows R;
+    WarmStart W = {{0, 0}, {0, 0}};
+    unsigned char order[kMaxRows];
+    auto rows = [&](int i) {
+        R.nC = nC;
+        for (int r = 2; r < nC; ++r) { R.a[r] = ga[(size_t)i * nC + r]; R.b[r] = gb[(size_t)i * nC + r]; R.c[r] = gc[(size_t)i * nC + r]; }
+        R.low0 = glow[2 * i]; R.high0 = ghigh[2 * i]; R.low1 = glow[2 * i + 1]; R.high1 = ghigh[2 * i + 1];
+    };
+    double *Xb = X + (size_t)b * 2 * (N + 1), *Lb = L + (size_t)b * 2 * (N + 1);
+    for (int i = 0; i <= N; ++i) {  // feasible sets (:131-164), on the same wrapper object
+        const bool last = i == N;
+        rows(i);
+        set_next_rows(R, last, last ? 0.0 : deltas[i], -kFeasMaxX, kFeasMaxX);
+        double uu, lo, hi;
+        stage_solve(R, W, 1e-9, 1.0, -kFeasMaxX, kFeasMaxX, 1, order, uu, lo);
+        stage_solve(R, W, -1e-9, -1.0, -kFeasMaxX, kFeasMaxX, 1, order, uu, hi);
+        if (lo < 0) lo = 0;
+        Xb[2 * i] = lo; Xb[2 * i + 1] = hi;
+    }
+    for (int i = 0; i <= N; ++i) { Lb[2 * i] = 0.0; Lb[2 * i + 1] = 0.0; }
+    double l0 = sdmin[b] * sdmin[b], l1 = sdmax[b] * sdmax[b];
+    Lb[0] = l0; Lb[1] = l1;
+    for (int i = 0; i < N; ++i) {
+        const double delta = deltas[i];
+        const double dprev = i > 0 ? deltas[i - 1] : deltas[N - 1];  // get_deltas()[i - 1]: Python's negative index at i = 0
+        double lo, hi;
+        if (isnan(l0) || isnan(l1)) { lo = qnan(); hi = qnan(); }
+        else {
+            rows(i);
+            set_next_rows(R, false, delta, Xb[2 * (i + 1)], Xb[2 * (i + 1) + 1]);
+            double uu, xx;
+            stage_solve(R, W, -2 * dprev, -1.0, l0, l1, 1, order, uu, xx);
+            hi = xx + 2 * dprev * uu;
+            stage_solve(R, W, 2 * dprev, 1.0, l0, l1, 1, order, uu, xx);
+            lo = xx + 2 * dprev * uu;
+        }
+        if (lo < 0) lo = 0;
+        Lb[2 * (i + 1)] = lo; Lb[2 * (i + 1) + 1] = hi;
+        if (isnan(lo) || isnan(hi)) break;
+        l0 = lo; l1 = hi;
+    }
+}
+}  // namespace tpr
+
 namespace {
 int check_dense(const tpr_dense_problem *p) {
     if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
@@ -1027,6 +1083,32 @@ int tpr_solve_desired_duration_dense_batch(const tpr_dense_problem *p, const dou
             hipLaunchKernelGGL(tpr::sd_blend_kernel, dim3(A.B), dim3(64), 0, stream, G);
         }
     }
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
+int tpr_reachable_sets_dense_batch(const tpr_dense_problem *p, const double *sdmin, const double *sdmax, double *L, double *X,
+                                   void *stream_) {
+    if (int rc = check_dense(p)) return rc;
+    if (!sdmin || !sdmax || !L) return fail(TPR_E_BADARG, "sdmin/sdmax/L are required");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->a));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    tpr::DenseArgs A = stage_dense(p, S);
+    const size_t B = (size_t)p->B, N = (size_t)p->N;
+    const double *dmin = S.in(sdmin, B), *dmax = S.in(sdmax, B);
+    double *dL = S.out(L, B * (N + 1) * 2);
+    double *dX = S.out(X, B * (N + 1) * 2);
+    if (!dX && B > 0) {  // the feasible sets are an intermediate when the caller does not ask for them
+        void *ws = nullptr;
+        if (S.err == hipSuccess) S.err = hipMallocAsync(&ws, B * (N + 1) * 2 * sizeof(double), stream);
+        if (S.err == hipSuccess) S.owned.push_back(ws);
+        dX = static_cast<double *>(ws);
+    }
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    if (A.B > 0)
+        hipLaunchKernelGGL(tpr::lane_dense_reachable_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dmin, dmax, dL, dX);
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }

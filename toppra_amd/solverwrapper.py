@@ -227,7 +227,7 @@ class hipDenseSeidelWrapper(SolverWrapper):
     the reference, flattened by :func:`dense_rows`, and the passes run on the dense-row entries of the library
     (tpr_*_dense_batch: rows across lanes, the reference's full Seidel iteration).  Every pass starts from a fresh
     object's warm-start state (compute_trajectory on a new instance -- the usual flow -- returns the reference's bits).
-    TOPPRAsd runs here too; reachable sets exist for velocity + acceleration problems only."""
+    TOPPRAsd and reachable sets run here too."""
 
     def __init__(self, constraint_list, path, path_discretization, solve_lp1d=1):
         self.constraints = constraint_list
@@ -307,7 +307,9 @@ class hipDenseSeidelWrapper(SolverWrapper):
         return var
 
     def reachable_sets(self, sdmin, sdmax):
-        raise NotImplementedError("reachable sets are implemented for velocity + acceleration constraints (hipSeidelWrapper)")
+        L, X = batch.reachable_sets_dense_batch(*self._rows, np.array([sdmin], dtype=np.float64),
+                                                np.array([sdmax], dtype=np.float64), want_X=True)
+        return L[0], X[0]
 
     def parameterization_sd(self, sd_start, sd_end, desired_duration, atol=1e-5):
         out = batch.solve_desired_duration_dense_batch(*self._rows, desired_duration, np.array([sd_start], dtype=np.float64),
