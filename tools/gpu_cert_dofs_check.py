@@ -74,6 +74,7 @@ def main():
         ms3 = tb.solve_batch_timed(*dv, out3, 3, variant=3)
         same = all(bool(torch.equal(torch.nan_to_num(out[k].double(), nan=-7.0), torch.nan_to_num(out3[k].double(), nan=-7.0))) for k in ("K", "sd2", "u", "status"))
         print("time     65536 x %2d x 200: family 3 %.3f ms, family 2 %.3f ms, identical %s" % (d, ms3, ms2, same), flush=True)
+        del dv, out, out3
     # above family 3's range: rows across 16 lanes (family 2) up to 16 dof, one trajectory per wave (family 4) up to 32
     for d, B in (() if quick else ((14, 65536), (16, 65536), (24, 16384), (32, 16384))):
         data = tb.make_synthetic_batch(B, d, 200)
@@ -82,7 +83,7 @@ def main():
         ms = tb.solve_batch_timed(*dv, out, 3)
         print("time     %5d x %2d x 200: auto (family %s) %.3f ms, ok fraction %.3f" % (B, d, "2" if d <= 16 else "4", ms,
                                                                                float((out["status"] == 0).double().mean())), flush=True)
-        del dv, out, out3
+        del dv, out
     print("checks %d, mismatching %d" % (checks, bad_total))
     return 1 if bad_total else 0
 
