@@ -200,6 +200,9 @@ typedef struct tpr_dense_problem {
     const double *low, *high;        /* [B][N+1][2]  variable boxes (u, x) */
     const double *deltas;            /* [B][N] */
     const double *sd_start, *sd_end; /* [B] or NULL (zeros) */
+    int32_t *active;                 /* [B][4] or NULL: the wrapper object's warm-start state (active_c_up[2], active_c_down[2]),
+                                        read at the start of a pass and written back at its end (as tpr_problem.active): passes
+                                        chained on ONE object pivot in the reference's order.  NULL = a fresh object. */
 } tpr_dense_problem;
 
 /* compute_parameterization (reachability_algorithm.py:240-376): outputs and status codes as tpr_solve_batch (r->K is

@@ -15,7 +15,7 @@ def batch_fixtures():
 
 
 def dense_fixtures():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "dense_*.npz")))
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "dense_*.npz")) if "reuse" not in os.path.basename(p))
 
 
 def torque_model(mass, grav, cori):

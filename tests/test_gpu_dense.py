@@ -245,3 +245,38 @@ def test_dense_desired_duration_vs_the_fused_path(gpu):
         assert_same(got[k], ref[k], k)
     assert np.array_equal(got["status"], ref["status"])
     assert np.any((ref["alpha"] > 0) & (ref["alpha"] < 1)) and np.any(ref["alpha"] == 1.0)
+
+
+def test_dense_passes_chained_on_one_instance(gpu):
+    """tests/golden/dense_reuse_d5_N60: compute_parameterization -> compute_feasible_sets -> compute_controllable_sets ->
+    compute_reachable_sets -> compute_parameterization on ONE reference instance with a torque constraint.  The wrapper
+    object's warm-start state (tpr_dense_problem.active: written by the 2-D LPs and by the 1-variable path of the forward
+    scan) is carried through toppra_amd's instance the same way: every pass returns the reference's bits (a fresh object
+    per pass would not, in 7 of the 16 trajectories) -- through the drop-in classes, and through the batch entries with
+    one `active` array for the whole batch."""
+    fx = golden("dense_reuse_d5_N60")
+    B = fx["a"].shape[0]
+    for b in range(B):
+        inst = ta.algorithm.TOPPRA(dense_constraints(fx, b, ta.constraint), ta.SplineInterpolator(fx["knots"], fx["way"][b]),
+                                   gridpoints=fx["grid"])
+        sdd, sd, _, K = inst.compute_parameterization(fx["sd_start"][b], fx["sd_end"][b], return_data=True)
+        assert_same(K, fx["K"][b], "K[%d]" % b); assert_same(sd, fx["sd"][b], "sd[%d]" % b); assert_same(sdd, fx["u"][b], "u[%d]" % b)
+        assert_same(inst.compute_feasible_sets(), fx["X"][b], "X[%d] after the parameterization" % b)
+        assert_same(inst.compute_controllable_sets(0.05, 0.4), fx["Kc"][b], "Kc[%d] after that" % b)
+        assert_same(inst.compute_reachable_sets(0.0, 0.3), fx["L"][b], "L[%d] after that" % b)
+        sdd, sd, _, K = inst.compute_parameterization(fx["sd_start"][b], fx["sd_end"][b], return_data=True)
+        assert_same(K, fx["K2"][b], "K[%d], second parameterization" % b)
+        assert_same(sd, fx["sd2nd"][b], "sd[%d], second parameterization" % b)
+        assert_same(sdd, fx["u2nd"][b], "u[%d], second parameterization" % b)
+    active = np.zeros((B, 4), dtype=np.int32)
+    got = batch.solve_dense_batch(*_rows(fx), fx["sd_start"], fx["sd_end"], want_sd=True, active=active)
+    assert_same(got["sd"], fx["sd"], "sd (batch)")
+    assert active.any()
+    assert_same(batch.feasible_sets_dense_batch(*_rows(fx), active=active), fx["X"], "X (batch, carried state)")
+    assert_same(batch.controllable_sets_dense_batch(*_rows(fx), np.full(B, 0.05), np.full(B, 0.4), active=active), fx["Kc"], "Kc (batch)")
+    assert_same(batch.reachable_sets_dense_batch(*_rows(fx), np.zeros(B), np.full(B, 0.3), active=active), fx["L"], "L (batch)")
+    again = batch.solve_dense_batch(*_rows(fx), fx["sd_start"], fx["sd_end"], want_sd=True, active=active)
+    assert_same(again["K"], fx["K2"], "K (batch, second parameterization)")
+    assert_same(again["sd"], fx["sd2nd"], "sd (batch, second parameterization)")
+    fresh = batch.feasible_sets_dense_batch(*_rows(fx))
+    assert not np.array_equal(fresh, fx["X"], equal_nan=True)   # the state matters: a fresh object returns other bits

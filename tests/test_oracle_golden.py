@@ -165,6 +165,25 @@ def test_dense_fixture_desired_duration(oracle, name):
     assert_same(got["u"], fx["sd_u"], "u")
 
 
+def test_dense_reuse_fixture(oracle):
+    """Passes chained on ONE reference instance with a torque constraint (parameterization -> feasible sets -> controllable
+    sets -> reachable sets -> parameterization): the oracle's DenseWrapper driven in the same order -- the warm-start state
+    carried from pass to pass changes bits in 7 of the 16 trajectories."""
+    fx = golden("dense_reuse_d5_N60")
+    assert int(fx["differs"]) >= 3
+    for b in range(fx["a"].shape[0]):
+        w = oracle.DenseWrapper(fx["a"][b], fx["b"][b], fx["c"][b], fx["low"][b], fx["high"][b], fx["deltas"])
+        st, sdd, sd, xs, K = w.compute_parameterization(float(fx["sd_start"][b]), float(fx["sd_end"][b]))
+        assert st == 0
+        assert_same(K, fx["K"][b], "K"); assert_same(sd, fx["sd"][b], "sd"); assert_same(sdd, fx["u"][b], "u")
+        assert_same(w.compute_feasible_sets(), fx["X"][b], "X after the parameterization")
+        assert_same(w.compute_controllable_sets(0.05, 0.4), fx["Kc"][b], "controllable sets after that")
+        assert_same(w.compute_reachable_sets(0.0, 0.3)[0], fx["L"][b], "reachable sets after that")
+        st, sdd, sd, xs, K = w.compute_parameterization(float(fx["sd_start"][b]), float(fx["sd_end"][b]))
+        assert_same(K, fx["K2"][b], "K, second parameterization"); assert_same(sd, fx["sd2nd"][b], "sd, second parameterization")
+        assert_same(sdd, fx["u2nd"][b], "u, second parameterization")
+
+
 def test_dense_rows_from_the_mirror_constraint_classes():
     """toppra_amd's own SecondOrderConstraint / JointTorqueConstraint (host numpy through the user's inverse dynamics, as in
     the reference) + dense_rows against the rows the REFERENCE's constraint objects gave (fixtures without a velocity /

@@ -500,7 +500,56 @@ def dense_fixture(name, B, d, N, seed, kinds, scheme, sd_mode="zero"):
     print(name, "nC", rec["a"].shape[2], "status counts", np.bincount(rec["status"], minlength=3))
 
 
+def dense_reuse_fixture(name="dense_reuse_d5_N60", B=16, d=5, N=60, seed=75):
+    """Passes chained on ONE reference instance with a torque constraint, in script order: compute_parameterization ->
+    compute_feasible_sets -> compute_controllable_sets -> compute_reachable_sets -> compute_parameterization again.  The
+    wrapper object's warm-start state (active_c_up / active_c_down, written by the 2-D LPs and by the 1-variable path of
+    the forward scan) is carried from pass to pass; `differs` counts the trajectories where a fresh instance would have
+    returned other bits for the second and later passes."""
+    from toppra_amd.solverwrapper import dense_rows
+    rng = np.random.default_rng(seed)
+    knots, grid = np.linspace(0, 1, 5), np.linspace(0, 1, N + 1)
+    way = rng.standard_normal((B, 5, d))
+    mass, grav, cori = 1.0 + rng.random((B, d)), 0.5 * rng.standard_normal((B, d)), 0.3 * rng.standard_normal((B, d))
+    taumax, fric = 6.0 + 6.0 * rng.random((B, d)), 0.1 * rng.random((B, d))
+    vmax, amax = 10 + 20 * rng.random((B, d)), 10 + 2 * rng.random((B, d))
+    sd0, sd1 = 0.1 * rng.random(B), 0.1 * rng.random(B)
+    out = {}
+    differs = 0
+    for b in range(B):
+        path = ta.SplineInterpolator(knots, way[b])
+        inv_dyn = torque_model(mass[b], grav[b], cori[b])
+        cons = [constraint.JointVelocityConstraint(np.stack([-vmax[b], vmax[b]], axis=1)),
+                constraint.JointAccelerationConstraint(np.stack([-amax[b], amax[b]], axis=1)),
+                constraint.JointTorqueConstraint(inv_dyn, np.stack([-taumax[b], taumax[b]], axis=1), fric[b],
+                                                 discretization_scheme=constraint.DiscretizationType.Interpolation)]
+        inst = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        sdd, sd, _, K = inst.compute_parameterization(sd0[b], sd1[b], return_data=True)
+        assert sd is not None
+        X = inst.compute_feasible_sets()
+        Kc = inst.compute_controllable_sets(0.05, 0.4)
+        L = inst.compute_reachable_sets(0.0, 0.3)
+        sdd2, sd2v, _, K2 = inst.compute_parameterization(sd0[b], sd1[b], return_data=True)
+        fresh = lambda: algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")  # noqa: E731
+        same = (np.array_equal(X, fresh().compute_feasible_sets(), equal_nan=True)
+                and np.array_equal(Kc, fresh().compute_controllable_sets(0.05, 0.4), equal_nan=True)
+                and np.array_equal(L, fresh().compute_reachable_sets(0.0, 0.3), equal_nan=True)
+                and np.array_equal(K2, K, equal_nan=True) and np.array_equal(sd2v, sd, equal_nan=True))
+        differs += not same
+        rows = dense_rows(cons, path, grid)
+        for k, val in (("a", rows["a"]), ("b", rows["b"]), ("c", rows["c"]), ("low", rows["low"]), ("high", rows["high"]), ("K", K),
+                       ("sd", sd), ("u", sdd), ("X", X), ("Kc", Kc), ("L", L), ("K2", K2), ("sd2nd", sd2v), ("u2nd", sdd2)):
+            out.setdefault(k, []).append(val)
+    rec = {k: np.stack(v) for k, v in out.items()}
+    rec.update(deltas=np.diff(grid), grid=grid, knots=knots, way=way, mass=mass, grav=grav, cori=cori, taumax=taumax, fric=fric,
+               vmax=vmax, amax=amax, sd_start=sd0, sd_end=sd1, scheme=np.array(1), kinds=np.array("vel,acc,torque"),
+               differs=np.array(differs))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, "nC", rec["a"].shape[2], "trajectories where the carried state changes bits:", differs, "of", B)
+
+
 def dense_fixtures():
+    dense_reuse_fixture()
     dense_fixture("dense_torque_d5_N40_collocation", 8, 5, 40, seed=71, kinds=("vel", "torque"), scheme=0)
     dense_fixture("dense_vel_acc_second_d6_N50", 6, 6, 50, seed=72, kinds=("vel", "acc", "second"), scheme=1, sd_mode="random")
     dense_fixture("dense_torque_only_d3_N30", 8, 3, 30, seed=73, kinds=("torque",), scheme=1, sd_mode="random")

@@ -51,7 +51,7 @@ class tpr_dense_problem(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("nC", C.c_int32), ("flags", C.c_int32),
                 ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p),
                 ("low", C.c_void_p), ("high", C.c_void_p), ("deltas", C.c_void_p),
-                ("sd_start", C.c_void_p), ("sd_end", C.c_void_p)]
+                ("sd_start", C.c_void_p), ("sd_end", C.c_void_p), ("active", C.c_void_p)]
 
 
 EXPORTS = (
@@ -217,11 +217,11 @@ def _per_traj(name, arr, B, like, dev):
     return np.ascontiguousarray(arr)
 
 
-def make_dense_problem(a, b, c, low, high, deltas, sd_start=None, sd_end=None, squared=False, keep=None):
+def make_dense_problem(a, b, c, low, high, deltas, sd_start=None, sd_end=None, squared=False, keep=None, active=None):
     """Build a tpr_dense_problem from the arrays of the reference's seidelWrapper (all numpy or all torch-CUDA):
     a, b, c [B, N+1, nC] (a_arr, b_arr, c_arr: nC counts the two reserved x_next rows), low, high [B, N+1, 2],
-    deltas [N] or [B, N], sd_start / sd_end scalars or [B].  Shapes and dtypes are validated here: the C-ABI takes raw
-    pointers."""
+    deltas [N] or [B, N], sd_start / sd_end scalars or [B], active [B, 4] int32 (the wrapper object's warm-start state,
+    in / out).  Shapes and dtypes are validated here: the C-ABI takes raw pointers."""
     dev = is_torch_cuda(a)
     keep = keep if keep is not None else []
     if dev:
@@ -264,6 +264,17 @@ def make_dense_problem(a, b, c, low, high, deltas, sd_start=None, sd_end=None, s
             arr = _per_traj(name, arr, B, a, dev)
             keep.append(arr)
             setattr(p, name, ptr(arr))
+    if active is not None:  # [B, 4] int32 warm-start state of the reference's wrapper object, updated in place
+        if dev:
+            import torch
+            if not (hasattr(active, "is_cuda") and active.is_cuda) or active.device != a.device or \
+                    active.dtype != torch.int32 or tuple(active.shape) != (B, 4) or not active.is_contiguous():
+                raise ValueError("active must be a contiguous int32 tensor [B, 4] on a's device")
+        elif not (isinstance(active, np.ndarray) and active.dtype == np.int32 and active.shape == (B, 4)
+                  and active.flags["C_CONTIGUOUS"]):
+            raise ValueError("active must be a C-contiguous int32 array [B, 4] (it is updated in place)")
+        keep.append(active)
+        p.active = ptr(active)
     return p, keep
 
 

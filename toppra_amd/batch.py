@@ -167,13 +167,14 @@ def controllable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interp
     return K
 
 
-def solve_dense_batch(a, b, c, low, high, deltas, sd_start=None, sd_end=None, want_sd=False, squared=False):
+def solve_dense_batch(a, b, c, low, high, deltas, sd_start=None, sd_end=None, want_sd=False, squared=False, active=None):
     """compute_parameterization on DENSE rows -- any canonical-linear constraint list, flattened as the reference's
     seidelWrapper flattens it (cy_seidel_solverwrapper.pyx:425-531; :func:`toppra_amd.solverwrapper.dense_rows` does it for
     constraint objects): a, b, c [B, N+1, nC], low, high [B, N+1, 2], deltas [N] or [B, N].  Returns the dict of
-    :func:`solve_batch`.  Every stage LP runs the reference's full Seidel iteration: the reference's bits."""
+    :func:`solve_batch`.  Every stage LP runs the reference's full Seidel iteration: the reference's bits.  ``active``
+    (int32 [B, 4], in / out; all dense entries): the wrapper object's warm-start state, for passes chained on one object."""
     _prepare(a)
-    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, sd_start, sd_end, squared=squared)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, sd_start, sd_end, squared=squared, active=active)
     out = {"sd2": _empty(a, (p.B, p.N + 1)), "u": _empty(a, (p.B, p.N)), "K": _empty(a, (p.B, p.N + 1, 2)),
            "status": _empty(a, (p.B,), "i32")}
     if want_sd:
@@ -184,11 +185,12 @@ def solve_dense_batch(a, b, c, low, high, deltas, sd_start=None, sd_end=None, wa
     return out
 
 
-def solve_desired_duration_dense_batch(a, b, c, low, high, deltas, desired_duration, sd_start=None, sd_end=None, atol=1e-5):
+def solve_desired_duration_dense_batch(a, b, c, low, high, deltas, desired_duration, sd_start=None, sd_end=None, atol=1e-5,
+                                       active=None):
     """TOPPRAsd.compute_parameterization on dense rows (see :func:`solve_dense_batch`, :func:`solve_desired_duration_batch`):
     dict(sd2, sd, u, K, status, alpha)."""
     _prepare(a)
-    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, sd_start, sd_end)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, sd_start, sd_end, active=active)
     B, N = p.B, p.N
     desired = _capi.per_traj_vector("desired_duration", desired_duration, B, a)
     out = {"sd2": _empty(a, (B, N + 1)), "sd": _empty(a, (B, N + 1)), "u": _empty(a, (B, N)),
@@ -200,10 +202,10 @@ def solve_desired_duration_dense_batch(a, b, c, low, high, deltas, desired_durat
     return out
 
 
-def controllable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, squared=False):
+def controllable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, squared=False, active=None):
     """compute_controllable_sets(sdmin, sdmax) on dense rows (see :func:`solve_dense_batch`) -> K [B, N+1, 2]."""
     _prepare(a)
-    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, squared=squared)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, squared=squared, active=active)
     sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, a)
     sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, a)
     K = _empty(a, (p.B, p.N + 1, 2))
@@ -212,11 +214,11 @@ def controllable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, squa
     return K
 
 
-def reachable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, want_X=False):
+def reachable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, want_X=False, active=None):
     """compute_reachable_sets(sdmin, sdmax) on dense rows (see :func:`solve_dense_batch`) -> L [B, N+1, 2] (and the feasible
     sets X it computes on the way with ``want_X``)."""
     _prepare(a)
-    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, active=active)
     sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, a)
     sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, a)
     L = _empty(a, (p.B, p.N + 1, 2))
@@ -226,10 +228,10 @@ def reachable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, want_X=
     return (L, X) if want_X else L
 
 
-def feasible_sets_dense_batch(a, b, c, low, high, deltas):
+def feasible_sets_dense_batch(a, b, c, low, high, deltas, active=None):
     """compute_feasible_sets on dense rows (see :func:`solve_dense_batch`) -> X [B, N+1, 2]."""
     _prepare(a)
-    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, active=active)
     X = _empty(a, (p.B, p.N + 1, 2))
     _capi.check(_capi.load().tpr_feasible_sets_dense_batch(C.byref(p), _capi.ptr(X), _stream_ptr(a)))
     return X

@@ -12,6 +12,7 @@ struct DenseArgs {
     int32_t *status;
     double *X;                   // feasible sets [B][N+1][2] (mode 2)
     int backward_only;
+    int32_t *active;             // [B][4] warm-start state of the wrapper object (active_c_up[2], active_c_down[2]), in / out; nullptr: a fresh object
     // TOPPRAsd: the fastest / slowest forward profiles x [B][N+1], u [B][N] (dense_sd_forward_kernel reads K and status)
     double *sd_xf, *sd_uf, *sd_xl, *sd_ul;
 };

@@ -955,6 +955,10 @@ static __global__ void __launch_bounds__(64) lane_dense_reachable_kernel(DenseAr
     const double *deltas = A.deltas + (size_t)b * N;
     StageRows R;
     WarmStart W = {{0, 0}, {0, 0}};
+    if (A.active) { const int32_t *st = A.active + (size_t)b * 4; W.up[0] = st[0]; W.up[1] = st[1]; W.down[0] = st[2]; W.down[1] = st[3]; }
+    auto put_state = [&]() {
+        if (A.active) { int32_t *st = A.active + (size_t)b * 4; st[0] = W.up[0]; st[1] = W.up[1]; st[2] = W.down[0]; st[3] = W.down[1]; }
+    };
     unsigned char order[kMaxRows];
     auto rows = [&](int i) {
         R.nC = nC;
@@ -994,6 +998,7 @@ static __global__ void __launch_bounds__(64) lane_dense_reachable_kernel(DenseAr
         if (isnan(lo) || isnan(hi)) break;
         l0 = lo; l1 = hi;
     }
+    put_state();
 }
 }  // namespace tpr
 
@@ -1013,6 +1018,7 @@ tpr::DenseArgs stage_dense(const tpr_dense_problem *p, Staging &S) {
     A.a = S.in(p->a, B * (N + 1) * nC); A.b = S.in(p->b, B * (N + 1) * nC); A.c = S.in(p->c, B * (N + 1) * nC);
     A.low = S.in(p->low, B * (N + 1) * 2); A.high = S.in(p->high, B * (N + 1) * 2);
     A.deltas = S.in(p->deltas, B * N);
+    A.active = S.out(p->active, B * 4, true);
     return A;
 }
 }  // namespace

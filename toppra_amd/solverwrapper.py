@@ -225,8 +225,8 @@ class hipDenseSeidelWrapper(SolverWrapper):
     """seidelWrapper for ANY list of canonical-linear constraints (SecondOrderConstraint, JointTorqueConstraint, the
     reference's own constraint objects, hand-written ones): the constraints' parameters are evaluated on the host, as in
     the reference, flattened by :func:`dense_rows`, and the passes run on the dense-row entries of the library
-    (tpr_*_dense_batch: rows across lanes, the reference's full Seidel iteration).  Every pass starts from a fresh
-    object's warm-start state (compute_trajectory on a new instance -- the usual flow -- returns the reference's bits).
+    (tpr_*_dense_batch: rows across lanes, the reference's full Seidel iteration).  The object's warm-start state is carried
+    from pass to pass as the reference object carries it.
     TOPPRAsd and reachable sets run here too."""
 
     def __init__(self, constraint_list, path, path_discretization, solve_lp1d=1):
@@ -247,18 +247,21 @@ class hipDenseSeidelWrapper(SolverWrapper):
             raise NotImplementedError("%d constraint rows per stage: the dense-row kernels hold 122" % self.nC)
         self._rows = tuple(np.ascontiguousarray(rows[k][None]) for k in ("a", "b", "c", "low", "high")) + (self.deltas,)
         self._solve_lp1d = int(solve_lp1d)
-        self._active_up, self._active_down = np.zeros(2, dtype=np.int32), np.zeros(2, dtype=np.int32)  # solve_stagewise_optim's state
+        # warm-start state of the two LP "solvers", as in the reference object: every pass and every per-stage call reads
+        # and updates it (tpr_dense_problem.active), so a sequence of calls on ONE instance pivots in the reference's order
+        self._active = np.zeros((1, 4), dtype=np.int32)
+        self._active_up, self._active_down = self._active[0, 0:2], self._active[0, 2:4]
 
     def controllable_sets(self, sdmin, sdmax):
         return batch.controllable_sets_dense_batch(*self._rows, np.array([sdmin ** 2], dtype=np.float64),
-                                                   np.array([sdmax ** 2], dtype=np.float64), squared=True)[0]
+                                                   np.array([sdmax ** 2], dtype=np.float64), squared=True, active=self._active)[0]
 
     def feasible_sets(self):
-        return batch.feasible_sets_dense_batch(*self._rows)[0]
+        return batch.feasible_sets_dense_batch(*self._rows, active=self._active)[0]
 
     def parameterization(self, sd_start, sd_end):
         out = batch.solve_dense_batch(*self._rows, np.array([sd_start ** 2], dtype=np.float64),
-                                      np.array([sd_end ** 2], dtype=np.float64), want_sd=True, squared=True)
+                                      np.array([sd_end ** 2], dtype=np.float64), want_sd=True, squared=True, active=self._active)
         res = {k: v[0] for k, v in out.items() if k != "status"}
         res["status"] = int(out["status"][0])
         return res
@@ -308,12 +311,12 @@ class hipDenseSeidelWrapper(SolverWrapper):
 
     def reachable_sets(self, sdmin, sdmax):
         L, X = batch.reachable_sets_dense_batch(*self._rows, np.array([sdmin], dtype=np.float64),
-                                                np.array([sdmax], dtype=np.float64), want_X=True)
+                                                np.array([sdmax], dtype=np.float64), want_X=True, active=self._active)
         return L[0], X[0]
 
     def parameterization_sd(self, sd_start, sd_end, desired_duration, atol=1e-5):
         out = batch.solve_desired_duration_dense_batch(*self._rows, desired_duration, np.array([sd_start], dtype=np.float64),
-                                                       np.array([sd_end], dtype=np.float64), atol)
+                                                       np.array([sd_end], dtype=np.float64), atol, active=self._active)
         return {k: v[0] for k, v in out.items()}
 
 
