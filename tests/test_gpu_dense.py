@@ -280,3 +280,19 @@ def test_dense_passes_chained_on_one_instance(gpu):
     assert_same(again["sd"], fx["sd2nd"], "sd (batch, second parameterization)")
     fresh = batch.feasible_sets_dense_batch(*_rows(fx))
     assert not np.array_equal(fresh, fx["X"], equal_nan=True)   # the state matters: a fresh object returns other bits
+
+
+def test_dense_rows_at_the_headline_shape(gpu):
+    """65 536 x 7 x 200 (BASELINE's headline batch), device-resident: the 9.5 GB of rows tpr_constraint_params_batch writes,
+    solved from those arrays (full iteration on every stage LP), against the fused default path (certified answers, rows
+    never materialised) -- every K, sd^2, u and return code of every trajectory."""
+    import torch
+    dev = torch.device("cuda", 0)
+    data = batch.make_synthetic_batch(65536, 7, 200)
+    dv = [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]
+    rows = batch.constraint_params_batch(*dv)
+    got = batch.solve_dense_batch(rows["a"], rows["b"], rows["c"], rows["low"], rows["high"], dv[2][1:] - dv[2][:-1])
+    ref = batch.solve_batch(*dv)
+    for k in ("K", "sd2", "u", "status"):
+        assert torch.equal(torch.nan_to_num(got[k].double(), nan=-7.0), torch.nan_to_num(ref[k].double(), nan=-7.0)), k
+    assert float((ref["status"] == 0).double().mean()) > 0.99
