@@ -219,3 +219,17 @@ def test_failed_trajectories_have_nan_durations(gpu, kind):
     if kind == "ParametrizeSpline":
         kt = np.asarray(traj._sp["knot_times"])
         assert np.isnan(kt[status != 0][:, 1:]).all()  # NaN time stamps, not a 5 s-per-gridpoint fiction
+
+
+@pytest.mark.parametrize("B,d,N", [(6, 3, 1100), (5, 17, 40), (4, 8, 600)])
+def test_param_spline_auto_falls_back_to_the_lapack_order_kernel(gpu, B, d, N):
+    """Beyond what the knot-parallel kernel holds in LDS (more than 1024 knots, more than 16 dof, more than 64 KB of
+    columns) the automatic choice is the LAPACK-order kernel: the same bits as variant 2, and variant 3 is refused."""
+    data = batch.make_synthetic_batch(B, d, N, seed=3)
+    sd = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], want_sd=True)["sd"]
+    auto = batch.param_spline_batch(data["coef"], data["breaks"], data["grid"], sd)
+    exact = batch.param_spline_batch(data["coef"], data["breaks"], data["grid"], sd, variant=2)
+    for k in ("counts", "knot_times", "coef"):
+        assert np.array_equal(auto[k], exact[k], equal_nan=True), k
+    with pytest.raises(Exception):
+        batch.param_spline_batch(data["coef"], data["breaks"], data["grid"], sd, variant=3)
