@@ -233,3 +233,30 @@ def test_param_spline_auto_falls_back_to_the_lapack_order_kernel(gpu, B, d, N):
         assert np.array_equal(auto[k], exact[k], equal_nan=True), k
     with pytest.raises(Exception):
         batch.param_spline_batch(data["coef"], data["breaks"], data["grid"], sd, variant=3)
+
+
+@pytest.mark.parametrize("name", ["param_batch_d6_N150", "param_batch_d3_N400"])
+def test_parametrizers_match_reference_on_a_batch(gpu, name):
+    """tests/golden/param_batch_*: the REFERENCE's ParametrizeSpline and ParametrizeConstAccel on a batch of time-optimal
+    profiles (some with boundary velocities), sampled at 97 times, orders 0 / 1 / 2.  From the fixture's sd (bit-identical
+    to what the solver returns here): the spline parametrizer through its default kernel (knot-parallel) and through the
+    LAPACK-order one, the constant-acceleration parametrizer -- durations at 1e-12 relative, samples at the rows' 1e-10
+    (relative to each order's range)."""
+    fx = golden(name)
+    sol = batch.solve_batch(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"], fx["sd_start"], fx["sd_end"], want_sd=True)
+    assert np.array_equal(sol["sd"], fx["sd"])
+    B = fx["coef"].shape[0]
+    for variant in (0, 2, 3):
+        sp = batch.param_spline_batch(fx["coef"], fx["breaks"], fx["grid"], fx["sd"], variant=variant)
+        dur = sp["knot_times"][np.arange(B), sp["counts"] - 1]
+        np.testing.assert_allclose(dur, fx["spl_duration"], rtol=1e-12, atol=0)
+        for order in (0, 1, 2):
+            q = batch.ppoly_eval_batch(sp["coef"], sp["knot_times"], fx["spl_times"], order, sp["counts"])
+            want = fx["spl_q%d" % order]
+            np.testing.assert_allclose(q, want, rtol=0, atol=1e-10 * max(1.0, float(np.abs(want).max())))
+    ts, us = batch.const_accel_times_batch(fx["grid"], fx["sd"])
+    np.testing.assert_allclose(ts[:, -1], fx["ca_duration"], rtol=1e-12, atol=0)
+    for order in (0, 1, 2):
+        q = batch.const_accel_eval_batch(fx["coef"], fx["breaks"], fx["grid"], fx["sd"], ts, us, fx["ca_times"], order)
+        want = fx["ca_q%d" % order]
+        np.testing.assert_allclose(q, want, rtol=0, atol=1e-10 * max(1.0, float(np.abs(want).max())))

@@ -500,6 +500,36 @@ def dense_fixture(name, B, d, N, seed, kinds, scheme, sd_mode="zero"):
     print(name, "nC", rec["a"].shape[2], "status counts", np.bincount(rec["status"], minlength=3))
 
 
+def parametrizer_fixture(name="param_batch_d6_N150", B=10, d=6, N=150, seed=81):
+    """The reference's output parametrizers on a batch: for each trajectory the time-optimal sd profile (boundary velocities
+    on some), then ParametrizeSpline (the default of compute_trajectory) and ParametrizeConstAccel sampled at 97 times,
+    orders 0 / 1 / 2, with their durations -- the f2 row's parity data beyond the single example trajectory."""
+    rng = np.random.default_rng(seed)
+    knots, grid = np.linspace(0, 1, 5), np.linspace(0, 1, N + 1)
+    way = rng.standard_normal((B, 5, d))
+    vmax, amax = 10 + 20 * rng.random((B, d)), 10 + 2 * rng.random((B, d))
+    sd0 = np.where(np.arange(B) % 3 == 1, 0.08, 0.0); sd1 = np.where(np.arange(B) % 3 == 2, 0.05, 0.0)
+    out = {k: [] for k in ("coef", "sd", "spl_duration", "spl_times", "spl_q0", "spl_q1", "spl_q2", "ca_duration", "ca_times",
+                           "ca_q0", "ca_q1", "ca_q2")}
+    for b in range(B):
+        path = ta.SplineInterpolator(knots, way[b])
+        cons = [constraint.JointVelocityConstraint(np.stack([-vmax[b], vmax[b]], 1)),
+                constraint.JointAccelerationConstraint(np.stack([-amax[b], amax[b]], 1))]
+        inst = algo.TOPPRA(cons, path, gridpoints=grid, solver_wrapper="seidel")
+        _, sd, _ = inst.compute_parameterization(sd0[b], sd1[b])
+        assert sd is not None
+        out["coef"].append(np.asarray(path.cspl.c)); out["sd"].append(sd)
+        for key, par in (("spl", ta.ParametrizeSpline(path, grid, sd)), ("ca", ta.ParametrizeConstAccel(path, grid, sd))):
+            ts = np.linspace(0, par.duration, 97)
+            out[key + "_duration"].append(par.duration); out[key + "_times"].append(ts)
+            for order in (0, 1, 2):
+                out[key + "_q%d" % order].append(par(ts, order))
+    rec = {k: np.stack(v) for k, v in out.items()}
+    rec.update(breaks=knots, grid=grid, vlim=np.stack([-vmax, vmax], -1), alim=np.stack([-amax, amax], -1), sd_start=sd0, sd_end=sd1)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, "durations", np.round(rec["spl_duration"], 3))
+
+
 def dense_reuse_fixture(name="dense_reuse_d5_N60", B=16, d=5, N=60, seed=75):
     """Passes chained on ONE reference instance with a torque constraint, in script order: compute_parameterization ->
     compute_feasible_sets -> compute_controllable_sets -> compute_reachable_sets -> compute_parameterization again.  The
@@ -575,6 +605,10 @@ if __name__ == "__main__":
         reachable_fixture()
         reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)
         raise SystemExit(0)
+    if "--param-only" in sys.argv:
+        parametrizer_fixture()
+        parametrizer_fixture("param_batch_d3_N400", B=6, d=3, N=400, seed=82)
+        raise SystemExit(0)
     if "--dense-only" in sys.argv:
         dense_fixtures()
         raise SystemExit(0)
@@ -601,6 +635,8 @@ if __name__ == "__main__":
     batch_fixture("batch_d14_N40_boundary", 6, 14, 40, seed=14, sd_mode="random")
     batch_fixture("batch_d16_N30", 4, 16, 30, seed=15)
     high_dof_fixtures()
+    parametrizer_fixture()
+    parametrizer_fixture("param_batch_d3_N400", B=6, d=3, N=400, seed=82)
     dense_fixtures()
     reachable_fixture()
     reachable_fixture("reach_d3_N40_collocation", B=16, d=3, N=40, seed=42, scheme=0)
