@@ -351,6 +351,11 @@ def end_to_end(torch, tb, dev, B=65536, d=7, N=200, samples=64):
         state["times"] = torch.linspace(0, 1, samples, dtype=torch.float64, device=dev).unsqueeze(0) * dur
         state["q"] = tb.ppoly_eval_batch(sp["coef"], sp["knot_times"], state["times"], 0, sp["counts"])
 
+    def sample_fused():
+        state["qs"] = tb.param_spline_sample_batch(state["coef"], state["breaks"], grid, state["sol"]["sd"], frac, orders=(0,))
+
+    frac = torch.linspace(0, 1, samples, dtype=torch.float64, device=dev)
+
     def timed(fn, reps=5):
         fn()
         torch.cuda.synchronize()
@@ -376,10 +381,19 @@ def end_to_end(torch, tb, dev, B=65536, d=7, N=200, samples=64):
         stages[name] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": gbps, "hbm_frac_of_8TBps_peak": gbps / 8000.0,
                         "hbm_frac_of_6.3TBps_achievable": gbps / 6300.0}
     total = sum(s["ms"] for s in stages.values())
+    # the same samples without the coefficient table in between (tpr_param_spline_sample_batch): fit + evaluation in one
+    # launch from LDS-resident knot derivatives
+    ms_fused = timed(sample_fused)
+    nb_fused = 8 * B * ((N + 1) + 4 * nseg * d + samples * d) + 8 * samples
+    same = bool(torch.equal(torch.nan_to_num(state["qs"]["q"], nan=-7.0), torch.nan_to_num(state["q"], nan=-7.0)))
+    fused = {"ms": ms_fused, "algorithmic_bytes": nb_fused, "GBps": nb_fused / (ms_fused * 1e-3) / 1e9,
+             "identical_bits_to_table_plus_evaluation": same,
+             "total_ms_with_it": stages["spline_fit"]["ms"] + stages["solve_sd_only"]["ms"] + ms_fused}
     ok = float((state["sol"]["status"] == 0).double().mean().item())
     finite = bool(torch.isfinite(state["q"][state["sol"]["status"] == 0]).all().item())
     return {"workload": "batch=%d, %d-DoF, 5 waypoints -> N=%d gridpoints -> %d samples of q(t) per trajectory; device-resident" % (B, d, N, samples),
             "stages": stages, "total_ms": total, "trajectories_per_s": B / total * 1e3, "ok_fraction": ok, "q_finite_where_ok": finite,
+            "sampled_without_the_table": fused, "trajectories_per_s_without_the_table": B / fused["total_ms_with_it"] * 1e3,
             "note": "param_spline writes the [B, 4, N, d] coefficient table (%.2f GB): the one HBM-bound stage of the pipeline "
                     "(6.3 TB/s achievable: MI355X_MICROARCH.md); ppoly_eval's bytes are what its samples need (a time, four coefficient "
                     "rows of d doubles and d outputs per sample, the breakpoints once): %d samples read a fraction of the table, at "

@@ -292,6 +292,14 @@ int tpr_const_accel_eval_batch(const tpr_problem *p, const double *sd, const dou
  * else 2, else 1.  Time stamps, counts and waypoints are the same bits in every variant.
  * tpr_ppoly_eval_batch evaluates such tables -- SplineInterpolator.__call__(t, order), i.e. scipy PPoly
  * (interpolator.py:423-430) -- at times [B][T] -> out [B][T][d]; breaks [B][nseg+1]; counts may be NULL.   */
+/* ParametrizeSpline + SplineInterpolator.__call__ in one launch: what a caller of compute_trajectory() does next
+ * (traj(ts), traj(ts, 1), traj(ts, 2): examples/plot_kinematics.py:52-57) without the [B][4][N][d] coefficient table in
+ * between -- the knot-parallel fit (variant 3 of tpr_param_spline_batch: d <= 16, knots in LDS) evaluates the samples from
+ * its LDS-resident knot derivatives; the same bits as tpr_param_spline_batch(variant 3) + tpr_ppoly_eval_batch.
+ * times [B][T] (times_per_traj) or [T]; fractions != 0: times are fractions of each trajectory's duration
+ * (linspace(0, 1, T) * duration).  q / qd / qdd [B][T][d] (order 0 / 1 / 2; any may be NULL), duration [B] (may be NULL). */
+int tpr_param_spline_sample_batch(const tpr_problem *p, const double *sd, int T, const double *times, int times_per_traj,
+                                  int fractions, double *q, double *qd, double *qdd, double *duration, void *stream);
 int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_times, int32_t *counts,
                            double *coef_t, void *stream);
 int tpr_ppoly_eval_batch(int B, int nseg, int d, const double *coef, const double *breaks, const int32_t *counts,

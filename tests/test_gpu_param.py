@@ -260,3 +260,36 @@ def test_parametrizers_match_reference_on_a_batch(gpu, name):
         q = batch.const_accel_eval_batch(fx["coef"], fx["breaks"], fx["grid"], fx["sd"], ts, us, fx["ca_times"], order)
         want = fx["ca_q%d" % order]
         np.testing.assert_allclose(q, want, rtol=0, atol=1e-10 * max(1.0, float(np.abs(want).max())))
+
+
+@pytest.mark.parametrize("B,d,N,T", [(300, 7, 200, 64), (40, 1, 64, 5), (33, 16, 100, 17), (20, 3, 600, 200), (64, 5, 3, 9), (16, 4, 1, 4)])
+def test_param_spline_sample_matches_table_plus_evaluation(gpu, B, d, N, T):
+    """tpr_param_spline_sample_batch (ParametrizeSpline evaluated at T times per trajectory without the coefficient table in
+    between) against tpr_param_spline_batch (variant 3) + tpr_ppoly_eval_batch: q, dq/dt, d2q/dt2 and the durations bit
+    for bit -- shared fractions of the duration, per-trajectory fractions, absolute times incl. times before 0 and past the
+    end (extrapolation from the end segments), ragged knot counts and single-knot trajectories."""
+    rng = np.random.default_rng(50 + d + N)
+    data = batch.make_synthetic_batch(B, d, N, seed=60 + d)
+    sd = batch.solve_batch(data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"], want_sd=True)["sd"]
+    sd = np.where(np.isnan(sd), 1.0, sd)
+    sd[rng.random(sd.shape) < 0.05] = 1e12          # dropped gridpoints: ragged knot vectors
+    sd[0] = 1e12                                     # a single knot
+    args = (data["coef"], data["breaks"], data["grid"], sd)
+    sp = batch.param_spline_batch(*args, variant=3)
+    dur = sp["knot_times"][np.arange(B), sp["counts"] - 1]
+    frac = np.linspace(0, 1, T)
+    cases = [(frac, True, frac[None] * dur[:, None]),
+             (rng.random((B, T)), True, None),
+             (dur[:, None] * rng.uniform(-0.2, 1.3, size=(B, T)), False, None)]
+    for times, fractions, absolute in cases:
+        if absolute is None:
+            absolute = times * dur[:, None] if fractions else times
+        got = batch.param_spline_sample_batch(*args, times, fractions=fractions, orders=(0, 1, 2))
+        assert np.array_equal(got["duration"], dur)
+        for order, key in ((0, "q"), (1, "qd"), (2, "qdd")):
+            want = batch.ppoly_eval_batch(sp["coef"], sp["knot_times"], np.ascontiguousarray(absolute), order, sp["counts"])
+            assert np.array_equal(got[key], want, equal_nan=True), (key, fractions)
+    only = batch.param_spline_sample_batch(*args, frac, orders=(1,))
+    assert set(only) == {"qd", "duration"}
+    with pytest.raises(Exception):
+        batch.param_spline_sample_batch(np.zeros((1, 4, 2, 17)), np.array([0.0, 0.5, 1.0]), np.linspace(0, 1, 5), np.ones((1, 5)), frac)

@@ -61,7 +61,7 @@ EXPORTS = (
     "tpr_spline_fit_batch", "tpr_const_accel_times_batch", "tpr_const_accel_eval_batch",
     "tpr_solve_desired_duration_batch", "tpr_robust_solve_batch", "tpr_param_spline_batch", "tpr_ppoly_eval_batch",
     "tpr_reachable_sets_batch", "tpr_solve_dense_batch", "tpr_controllable_sets_dense_batch", "tpr_feasible_sets_dense_batch",
-    "tpr_solve_desired_duration_dense_batch", "tpr_reachable_sets_dense_batch",
+    "tpr_solve_desired_duration_dense_batch", "tpr_reachable_sets_dense_batch", "tpr_param_spline_sample_batch",
 )
 
 _lib = None
@@ -126,6 +126,8 @@ def load():
         L.tpr_const_accel_times_batch.argtypes = [P, V, V, V, V]
         L.tpr_const_accel_eval_batch.restype = C.c_int
         L.tpr_const_accel_eval_batch.argtypes = [P, V, V, V, C.c_int, V, C.c_int, V, V]
+        L.tpr_param_spline_sample_batch.restype = C.c_int
+        L.tpr_param_spline_sample_batch.argtypes = [P, V, C.c_int, V, C.c_int, C.c_int, V, V, V, V, V]
         L.tpr_param_spline_batch.restype = C.c_int
         L.tpr_param_spline_batch.argtypes = [P, V, V, V, V, V]
         L.tpr_ppoly_eval_batch.restype = C.c_int

@@ -287,6 +287,19 @@ class BatchTOPPRA(object):
         raise NotImplementedError("parametrizer %r (ParametrizeSpline and ParametrizeConstAccel are available)" % (parametrizer,))
 
 
+    def compute_trajectory_samples(self, times, sd_start=None, sd_end=None, fractions=True, orders=(0,)):
+        """``traj = compute_trajectory(); traj(ts, order)`` (examples/plot_kinematics.py:48-57) for the batch WITHOUT the
+        spline's coefficient table in between (2.9 GB at 65536 x 7 x 200): parameterize, then q / dq/dt / d2q/dt2 of the
+        reference's default parametrizer (ParametrizeSpline) at ``times`` -- [T] fractions of each trajectory's duration
+        (``np.linspace(0, 1, T)``) or [B, T] (fractions, or absolute times with ``fractions=False``).  Returns
+        dict(q / qd / qdd [B, T, d] for the requested orders, duration [B], status [B]); the same bits as
+        ``compute_trajectory()`` followed by its evaluation.  Up to 16 dof."""
+        res = self.compute_parameterization(sd_start, sd_end, want_sd=True, want_K=False, want_u=False)
+        out = _batch.param_spline_sample_batch(self.coef, self.breaks, self.gridpoints, res["sd"], times, fractions=fractions,
+                                               orders=orders)
+        out["status"] = res["status"]
+        return out
+
     def compute_controllable_sets(self, sdmin, sdmax):
         return _batch.controllable_sets_batch(self.coef, self.breaks, self.gridpoints, self.vlim,
                                               self.alim, sdmin, sdmax, self.interpolation)

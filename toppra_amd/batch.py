@@ -358,6 +358,37 @@ def param_spline_batch(coef, breaks, grid, sd, variant=0):
     return out
 
 
+def param_spline_sample_batch(coef, breaks, grid, sd, times, fractions=True, orders=(0,)):
+    """ParametrizeSpline + its evaluation in ONE launch, without the [B, 4, N, d] coefficient table in between: what
+    ``traj = inst.compute_trajectory(); traj(ts, order)`` computes, for B trajectories.  ``times``: [T] (fractions of each
+    trajectory's duration: ``linspace(0, 1, T)``) or [B, T] (fractions, or absolute times with ``fractions=False``).
+    Returns dict(q / qd / qdd [B, T, d] for the requested ``orders``, duration [B]) -- the same bits as
+    :func:`param_spline_batch` (variant 3) followed by :func:`ppoly_eval_batch`.  d <= 16, knots in LDS."""
+    _prepare(coef)
+    p, keep = _capi.make_problem(coef, breaks, grid, None, None)
+    dev = _capi.is_torch_cuda(coef)
+    if dev:
+        _capi.check_tensor("sd", sd, coef)
+        _capi.check_tensor("times", times, coef)
+        sd, times = sd.contiguous(), times.contiguous()
+    else:
+        sd, times = _capi.f64(sd), _capi.f64(times)
+    if tuple(sd.shape) != (p.B, p.N + 1):
+        raise ValueError("sd must have shape [B, N+1] = [%d, %d]" % (p.B, p.N + 1))
+    if times.ndim not in (1, 2) or (times.ndim == 2 and int(times.shape[0]) != p.B):
+        raise ValueError("times must have shape [T] or [B, T]")
+    if times.ndim == 1 and not fractions:
+        raise ValueError("shared sample times must be fractions of each trajectory's duration")
+    T = int(times.shape[-1])
+    names = {0: "q", 1: "qd", 2: "qdd"}
+    out = {names[o]: _empty(coef, (p.B, T, p.d)) for o in orders}
+    out["duration"] = _empty(coef, (p.B,))
+    _capi.check(_capi.load().tpr_param_spline_sample_batch(
+        C.byref(p), _capi.ptr(sd), T, _capi.ptr(times), int(times.ndim == 2), int(bool(fractions)),
+        _capi.ptr(out.get("q")), _capi.ptr(out.get("qd")), _capi.ptr(out.get("qdd")), _capi.ptr(out["duration"]), _stream_ptr(coef)))
+    return out
+
+
 def ppoly_eval_batch(coef, breaks, times, order=0, counts=None):
     """SplineInterpolator.__call__(t, order) for B piecewise cubics with their own breakpoints:
     coef [B, 4, nseg, d], breaks [B, nseg+1], times [B, T] -> [B, T, d] (order 0 / 1 / 2; extrapolation from

@@ -1454,6 +1454,54 @@ int tpr_param_spline_batch(const tpr_problem *p, const double *sd, double *knot_
     return TPR_E_OK;
 }
 
+int tpr_param_spline_sample_batch(const tpr_problem *p, const double *sd, int T, const double *times, int times_per_traj,
+                                  int fractions, double *q, double *qd, double *qdd, double *duration, void *stream_) {
+    if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
+    if (!p || p->B < 0 || p->N < 1 || p->d < 1 || p->nseg < 1 || !p->coef || !p->breaks || !p->grid || !sd || !times || T < 0 ||
+        (!q && !qd && !qdd))
+        return fail(TPR_E_BADARG, "bad spline-sampling arguments");
+    if (!times_per_traj && !fractions) return fail(TPR_E_BADARG, "shared sample times must be fractions of each trajectory's duration");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceScope scope(call_device(p->flags & TPR_DEVICE_PTRS, p->coef));
+    if (scope.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(scope.err));
+    Staging S(p->flags & TPR_DEVICE_PTRS, stream);
+    const size_t B = (size_t)p->B, N = (size_t)p->N, d = (size_t)p->d, nseg = (size_t)p->nseg;
+    tpr::ParamSplineArgs K{};
+    K.B = p->B; K.N = p->N; K.d = p->d; K.nseg = p->nseg; K.flags = p->flags;
+    K.coef = S.in(p->coef, B * 4 * nseg * d);
+    K.breaks = S.in(p->breaks, ((p->flags & TPR_BREAKS_PER_TRAJ) ? B : 1) * (nseg + 1));
+    K.grid = S.in(p->grid, ((p->flags & TPR_GRID_PER_TRAJ) ? B : 1) * (N + 1));
+    K.sd = S.in(sd, B * (N + 1));
+    tpr::ParamSampleArgs Q{};
+    Q.T = T; Q.fractions = fractions; Q.times_per_traj = times_per_traj;
+    Q.times = S.in(times, (times_per_traj ? B : 1) * (size_t)T);
+    Q.q[0] = S.out(q, B * T * d); Q.q[1] = S.out(qd, B * T * d); Q.q[2] = S.out(qdd, B * T * d);
+    Q.duration = S.out(duration, B);
+    if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
+    const size_t lds = (1 + d + std::max<size_t>(d, 2)) * ((N + 1) | 1) * sizeof(double);
+    if (!(d <= 16 && N + 1 <= 1024 && lds <= kMaxDynamicLds - 256))
+        return fail(TPR_E_UNSUPPORTED, "spline sampling: d <= 16 and about (2 d + 1) (N + 1) doubles of LDS (<= 64 KB); use tpr_param_spline_batch + tpr_ppoly_eval_batch");
+    if (B > 0 && T > 0) {
+        const int kpt = N + 1 <= 256 ? 1 : (N + 1 <= 512 ? 2 : 4);
+        const dim3 grid((unsigned)B), block(256);
+#define TPR_PCRS_CASE(DD) \
+        case DD: \
+            if (kpt == 1) hipLaunchKernelGGL((tpr::param_spline_pcr_kernel<DD, 1, true>), grid, block, lds, stream, K, (double *)nullptr, 0, Q); \
+            else if (kpt == 2) hipLaunchKernelGGL((tpr::param_spline_pcr_kernel<DD, 2, true>), grid, block, lds, stream, K, (double *)nullptr, 0, Q); \
+            else hipLaunchKernelGGL((tpr::param_spline_pcr_kernel<DD, 4, true>), grid, block, lds, stream, K, (double *)nullptr, 0, Q); \
+            break
+        switch (p->d) {
+            TPR_PCRS_CASE(1); TPR_PCRS_CASE(2); TPR_PCRS_CASE(3); TPR_PCRS_CASE(4);
+            TPR_PCRS_CASE(5); TPR_PCRS_CASE(6); TPR_PCRS_CASE(7); TPR_PCRS_CASE(8);
+            TPR_PCRS_CASE(9); TPR_PCRS_CASE(10); TPR_PCRS_CASE(11); TPR_PCRS_CASE(12);
+            TPR_PCRS_CASE(13); TPR_PCRS_CASE(14); TPR_PCRS_CASE(15); TPR_PCRS_CASE(16);
+        }
+#undef TPR_PCRS_CASE
+    }
+    HIP_TRY(S.finish());
+    return TPR_E_OK;
+}
+
 int tpr_ppoly_eval_batch(int B, int nseg, int d, const double *coef, const double *breaks, const int32_t *counts, int T,
                          const double *times, int order, double *out, int device_ptrs, void *stream_) {
     if (g_device < 0) return fail(TPR_E_HIP, "tpr_init() has not succeeded");
