@@ -81,6 +81,8 @@ def main():
     sp = tb.param_spline_batch(dv[0], dv[1], dv[2], sol["sd"])
     times = torch.rand(B, 64, dtype=torch.float64, device=dev) * 2.0
     cases["ppoly_eval_65536x64"] = lambda: tb.ppoly_eval_batch(sp["coef"], sp["knot_times"], times, 0, sp["counts"])
+    frac = torch.linspace(0, 1, 64, dtype=torch.float64, device=dev)
+    cases["param_spline_sample_65536x64"] = lambda: tb.param_spline_sample_batch(dv[0], dv[1], dv[2], sol["sd"], frac)
     ts_us = tb.const_accel_times_batch(dv[2], sol["sd"])
     cases["const_accel_times_65536x200"] = lambda: tb.const_accel_times_batch(dv[2], sol["sd"])
     cases["const_accel_eval_65536x64"] = lambda: tb.const_accel_eval_batch(dv[0], dv[1], dv[2], sol["sd"], ts_us[0], ts_us[1], times, 0)
