@@ -172,11 +172,26 @@ def cpu_baseline(data, target_seconds=12.0):
             "sample": "first %d trajectories of the rank-0 batch x %d passes (%.1f s), oracle/seidel_oracle.c "
                       "(C restatement of the reference's seidel path, bit-exact with it) with OpenMP on %d threads (bound, one "
                       "per core: every CPU this container is allowed); per-thread arenas" % (n, reps, total, cores),
-            "reference_itself": {
-                "value": 180.0, "unit": "trajectories/s per core", "where": "build container, 1 core, Python+Cython seidel",
-                "note": "the reference cannot run on the GPU box: /root/reference is absent there and its sources may not be "
-                        "copied into this repository, so the timed baseline is the C port (which is ~70x faster per core "
-                        "than the reference because it has no Python call overhead -- a stronger baseline)"}}
+            "reference_itself": reference_rate()}
+
+
+def reference_rate():
+    """The reference's OWN rate (Python + Cython seidel path), measured in the build container by tools/time_reference.py
+    and committed under profiles/ -- REPLAYED here: the GPU box has no /root/reference."""
+    import glob
+    note = ("the reference cannot run on the GPU box: /root/reference is absent there and its sources may not be copied into "
+            "this repository, so the baseline timed in THIS run is the C port (~70x faster per core than the reference: no "
+            "Python call overhead -- a stronger baseline); the figures of this block were measured in the build container")
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_cpu_rate.json")))
+    if not cands:
+        return {"value": 180.0, "unit": "trajectories/s per core", "where": "build container, 1 core (round 1 probe)", "note": note}
+    with open(cands[-1]) as fh:
+        ref = json.load(fh)
+    return {"value": ref["pool"]["traj_per_s_per_core"], "unit": "trajectories/s per core (end to end: spline, constraints, TOPPRA, "
+            "compute_parameterization)", "all_cores": {"value": ref["pool"]["traj_per_s_sum_of_workers"], "processes": ref["pool"]["processes"]},
+            "compute_parameterization_only_single_core": ref["single_core"]["compute_parameterization_only_traj_per_s"],
+            "where": ref["where"], "date": ref["date"], "command": ref["command"],
+            "REPLAYED": "from profiles/%s, not measured in this run" % os.path.basename(cands[-1]), "note": note}
 
 
 TOL_PROBE = r"""
@@ -206,9 +221,16 @@ def tolerance_probe(B, d, N, seed, sd2, status):
     tmp = os.path.join(tempfile.gettempdir(), "tpr_tol_probe_%d.npy" % os.getpid())
     env = dict(os.environ, TOPPRA_HIP_LIB=lib)
     try:
-        outp = subprocess.run([sys.executable, "-c", TOL_PROBE % dict(root=ROOT, B=B, d=d, N=N, seed=seed, tmp=tmp)], env=env,
-                              capture_output=True, text=True, timeout=300)
-        ms = json.loads([l for l in outp.stdout.splitlines() if l.startswith("{")][-1])["kernel_ms"]
+        lines, outp = [], None
+        for _attempt in range(2):  # (one retry: the probe is a second process on a GPU this one still holds memory on)
+            outp = subprocess.run([sys.executable, "-c", TOL_PROBE % dict(root=ROOT, B=B, d=d, N=N, seed=seed, tmp=tmp)], env=env,
+                                  capture_output=True, text=True, timeout=300)
+            lines = [l for l in outp.stdout.splitlines() if l.startswith("{")]
+            if lines:
+                break
+        if not lines:
+            return {"error": "the probe process printed no result (exit code %s): %s" % (outp.returncode, outp.stderr.strip()[-400:])}
+        ms = json.loads(lines[-1])["kernel_ms"]
         tol_sd2, tol_status = np.load(tmp), np.load(tmp + ".status.npy")
     except Exception as exc:  # a failed probe must not take the bench line with it
         return {"error": repr(exc)[:200]}
@@ -223,7 +245,7 @@ def tolerance_probe(B, d, N, seed, sd2, status):
             "note": "NOT the product: measurement build answering 'what does bit-exactness cost' (the product replicates the "
                     "reference's last-pivot arithmetic FMA-free with correctly rounded divisions; this build returns the "
                     "certified vertex itself, with contracted multiply-adds and reciprocal division).  The north star's bar is "
-                    "1e-8 on sd^2; tools/gpu_tolerance_report.py checks every fixture (profiles/r03_tolerance_report.json)"}
+                    "1e-8 on sd^2; tools/gpu_tolerance_report.py checks every fixture (profiles/r04_tolerance_report.json)"}
 
 
 def baseline_configs(torch, tb, dev):
@@ -400,6 +422,20 @@ def end_to_end(torch, tb, dev, B=65536, d=7, N=200, samples=64):
                     "cache-line granularity" % (8 * B * 4 * N * d / 1e9, samples)}
 
 
+def self_launch(n):
+    """Re-run this command line under torch.distributed.run with n ranks on this node; returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -428,6 +464,10 @@ def main():
                          "kernel statistics cover the headline mode only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves, exactly as the driver's own command would
+        # (one process per GPU over RCCL, 127.0.0.1 rendezvous on a free port); rank 0 of the child job prints the line
+        raise SystemExit(self_launch(args.gpus))
     import torch
     import torch.distributed as dist
     stub = args.stub_solver
@@ -448,9 +488,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if world != args.gpus and "WORLD_SIZE" in os.environ:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if args.rehearsal:
         local_rank = 0
     if stub:
@@ -655,11 +694,17 @@ def main():
             },
             "ok_fraction": ok_frac,
             "roofline": {
-                "bound": "hbm",
+                # what BINDS the kernel is fp64 VALU instruction issue (roofline_compute; no MFMA on this path: no dense
+                # contraction); the figures of this object are the HBM ones the contract defines -- algorithmic bytes per
+                # launch / kernel time measured in this run against the 8 TB/s peak -- kept because BASELINE's target is
+                # quoted against HBM
+                "bound": "valu_issue",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "hbm_frac": achieved / HBM_PEAK_GBS,
+                "binding_resource_frac": (compute_roofline(pmc, kernel_ms) or {}).get("frac"),
                 "traffic": pmc["bytes_per_launch"] if pmc else None,
                 "algorithmic_bytes_per_launch": bytes_per_traj * B,
                 "kernel_ms": kernel_ms,

@@ -159,3 +159,26 @@ def test_bench_multi_rank_control_flow_world8(gather):
     else:
         assert placement["chosen"] == gather
     assert line["stub_gather_delivered_every_ranks_last_step"] is True
+
+
+def test_bench_launches_its_own_ranks_world8():
+    """Plain `python bench.py --gpus 8 --stub-solver` with NO launcher and no rank variables in the environment (the way the
+    driver runs the N = 1 bench): bench.py must start the eight ranks itself and still print exactly one JSON line."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    try:
+        pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--stub-solver", "--steps", "3",
+                             "--warmup", "2", "--batch", "19", "--gridpoints", "12"], env=env, capture_output=True, text=True,
+                            timeout=300)
+    except subprocess.TimeoutExpired:
+        pytest.fail("plain `bench.py --gpus 8 --stub-solver` hung")
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8 * 19 and line["steps"] == 3
+    assert line["stub_gather_delivered_every_ranks_last_step"] is True
