@@ -105,9 +105,10 @@ typedef struct tpr_problem {
                         1-D path (:646-649).  Read at the start and updated at the end of tpr_solve_batch,
                         tpr_controllable_sets_batch and tpr_feasible_sets_batch, so that a sequence of passes on one
                         object (examples/plot_kinematics.py:48,72) returns the reference's bits.  Maintained by kernel
-                        family 4 (auto-selected when set); where that family cannot take the problem (N > 1480) or
-                        another variant is forced, the pass starts from a fresh object's state and leaves the array
-                        untouched.  The other entries ignore it (tpr_solve_stagewise_batch takes its own argument). */
+                        family 4 (auto-selected when set) and, where that family cannot take the problem (N > 1480),
+                        by the generic lane kernel (family 1, auto-selected then); forcing variant 2 or 3 together
+                        with a non-NULL state is refused (TPR_E_UNSUPPORTED): those families neither read nor update
+                        it.  The other entries ignore it (tpr_solve_stagewise_batch takes its own argument). */
 } tpr_problem;
 
 typedef struct tpr_result {
@@ -132,6 +133,12 @@ int tpr_init(int device);
 int tpr_device_count(void);
 const char *tpr_last_error(void);
 const char *tpr_version(void);
+/* ABI guard (0.2): the structures of this header grow at their END from version to version (tpr_problem.active and
+ * tpr_dense_problem.active joined in 0.2); a binding built against an older header would hand over a shorter structure
+ * and the library would read past it.  A binding compares these sizes (bytes of tpr_problem, tpr_result,
+ * tpr_dense_problem; NULL to skip one) with its own declarations before its first compute call.  Returns the ABI
+ * revision (2).                                                                                                      */
+int tpr_abi_sizes(int32_t *problem_bytes, int32_t *result_bytes, int32_t *dense_problem_bytes);
 
 /* Replaces ReachabilityAlgorithm.compute_parameterization (+ TOPPRA._forward_step) for B
  * trajectories: algorithm/reachabilitybased/reachability_algorithm.py:240-376,

@@ -306,3 +306,39 @@ def test_boundary_velocities_squared_like_the_reference(gpu):
         assert_same(fresh.compute_controllable_sets(float(fx["sdmin"][b]), float(fx["sdmax"][b])), fx["Kc"][b], "Kc[%d]" % b)
     dev = batch.solve_batch(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"], fx["sd_start"], fx["sd_end"])
     assert (dev["K"][:, N, 0] != fx["K"][:, N, 0]).all()  # sd * sd on the device: the other rounding of the same square
+
+
+def test_warm_start_state_on_long_grids_and_forced_variants(gpu, oracle):
+    """tpr_problem.active where kernel family 4 cannot take the problem (N > 1480: its per-trajectory tables no longer fit
+    the LDS): the generic lane kernel (family 1) carries the state instead -- the chain compute_parameterization ->
+    compute_feasible_sets -> compute_controllable_sets -> compute_parameterization on one object, against the oracle's
+    wrapper objects, states included; forcing a family that does not maintain the state is refused, not ignored."""
+    from toppra_amd import _capi
+    B, d, N = 6, 3, 1600
+    data = batch.make_synthetic_batch(B, d, N, seed=61)
+    args = (data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"])
+    active = np.zeros((B, 4), dtype=np.int32)
+    sd1 = np.array([0.0, 0.1, 0.0, 0.2, 0.0, 0.05])
+    out1 = batch.solve_batch(*args, None, sd1, active=active)
+    X = batch.feasible_sets_batch(*args, active=active)
+    K2 = batch.controllable_sets_batch(*args, np.zeros(B), 0.3 * np.ones(B), active=active)
+    out3 = batch.solve_batch(*args, None, sd1, active=active)
+    changed = 0
+    for b in range(B):
+        w = oracle.Wrapper(data["coef"][b], data["breaks"], data["grid"], data["vlim"][b], data["alim"][b])
+        st, sdd, sd, xs, K = w.compute_parameterization(0.0, float(sd1[b]))
+        assert st == out1["status"][b] and np.array_equal(K, out1["K"][b], equal_nan=True), b
+        assert np.array_equal(w.compute_feasible_sets(), X[b], equal_nan=True), b
+        assert np.array_equal(w.compute_controllable_sets(0.0, 0.3), K2[b], equal_nan=True), b
+        st, sdd, sd, xs, K = w.compute_parameterization(0.0, float(sd1[b]))
+        assert st == out3["status"][b] and np.array_equal(K, out3["K"][b], equal_nan=True), b
+        if st == 0:
+            assert np.array_equal(xs, out3["sd2"][b]) and np.array_equal(sdd, out3["u"][b]), b
+        assert np.array_equal(w.active(), active[b]), (b, w.active(), active[b])
+        changed += bool(active[b].any())
+    assert changed == B
+    small = batch.make_synthetic_batch(4, 3, 40, seed=62)
+    sargs = (small["coef"], small["breaks"], small["grid"], small["vlim"], small["alim"])
+    for variant in (2, 3):
+        with pytest.raises(_capi.ToppraHipError):
+            batch.solve_batch(*sargs, active=np.zeros((4, 4), dtype=np.int32), variant=variant)

@@ -55,7 +55,7 @@ class tpr_dense_problem(C.Structure):
 
 
 EXPORTS = (
-    "tpr_init", "tpr_device_count", "tpr_last_error", "tpr_version", "tpr_solve_batch",
+    "tpr_init", "tpr_device_count", "tpr_last_error", "tpr_version", "tpr_abi_sizes", "tpr_solve_batch",
     "tpr_controllable_sets_batch", "tpr_feasible_sets_batch", "tpr_constraint_params_batch",
     "tpr_solve_stagewise_batch", "tpr_lp1d_batch", "tpr_lp2d_batch", "tpr_solve_batch_timed",
     "tpr_spline_fit_batch", "tpr_const_accel_times_batch", "tpr_const_accel_eval_batch",
@@ -100,6 +100,14 @@ def load():
         L.tpr_device_count.restype = C.c_int
         L.tpr_last_error.restype = C.c_char_p
         L.tpr_version.restype = C.c_char_p
+        L.tpr_abi_sizes.restype = C.c_int
+        L.tpr_abi_sizes.argtypes = [C.POINTER(C.c_int32)] * 3
+        sizes = [C.c_int32(0), C.c_int32(0), C.c_int32(0)]
+        L.tpr_abi_sizes(*[C.byref(v) for v in sizes])
+        mine = [C.sizeof(tpr_problem), C.sizeof(tpr_result), C.sizeof(tpr_dense_problem)]
+        if [v.value for v in sizes] != mine:
+            raise ToppraHipError("libtoppra_hip.so was built from another header: its tpr_problem / tpr_result / "
+                                 "tpr_dense_problem take %s bytes, this binding declares %s" % ([v.value for v in sizes], mine))
         P, R, V = C.POINTER(tpr_problem), C.POINTER(tpr_result), C.c_void_p
         L.tpr_solve_batch.restype = C.c_int
         L.tpr_solve_batch.argtypes = [P, R, V]

@@ -94,15 +94,16 @@ def solve_batch(coef, breaks, grid, vlim, alim, sd_start=None, sd_end=None, inte
 
 
 def solve_desired_duration_batch(coef, breaks, grid, vlim, alim, desired_duration, sd_start=None, sd_end=None,
-                                 atol=1e-5, variant=0, interpolation=True):
+                                 atol=1e-5, variant=0, interpolation=True, squared=False):
     """TOPPRAsd.compute_parameterization for B trajectories (desired_duration_algorithm.py:42-191).
 
     ``desired_duration``: scalar or [B] seconds.  Returns dict(sd2, sd, u, K, status, alpha): alpha is
     the blend between the fastest (1) and slowest (0) parameterizations found by bisection.
     ``variant``: 0 = auto (from 14336 trajectories up to 8 dof, 20480 at 9..13 dof: the certified lane kernel runs the backward scan and both
-    forward profiles in one launch; rows across lanes otherwise), 2 / 3 force one."""
+    forward profiles in one launch; rows across lanes otherwise), 2 / 3 force one.  ``squared``: sd_start / sd_end already
+    hold sd^2 (TPR_BOUNDARY_SQUARED)."""
     _prepare(coef)
-    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation, variant=variant)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, sd_start, sd_end, interpolation, variant=variant, squared=squared)
     B, N = p.B, p.N
     desired = _capi.per_traj_vector("desired_duration", desired_duration, B, coef)
     out = {"sd2": _empty(coef, (B, N + 1)), "sd": _empty(coef, (B, N + 1)), "u": _empty(coef, (B, N)),
@@ -186,11 +187,11 @@ def solve_dense_batch(a, b, c, low, high, deltas, sd_start=None, sd_end=None, wa
 
 
 def solve_desired_duration_dense_batch(a, b, c, low, high, deltas, desired_duration, sd_start=None, sd_end=None, atol=1e-5,
-                                       active=None):
+                                       active=None, squared=False):
     """TOPPRAsd.compute_parameterization on dense rows (see :func:`solve_dense_batch`, :func:`solve_desired_duration_batch`):
     dict(sd2, sd, u, K, status, alpha)."""
     _prepare(a)
-    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, sd_start, sd_end, active=active)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, sd_start, sd_end, active=active, squared=squared)
     B, N = p.B, p.N
     desired = _capi.per_traj_vector("desired_duration", desired_duration, B, a)
     out = {"sd2": _empty(a, (B, N + 1)), "sd": _empty(a, (B, N + 1)), "u": _empty(a, (B, N)),
@@ -214,11 +215,11 @@ def controllable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, squa
     return K
 
 
-def reachable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, want_X=False, active=None):
+def reachable_sets_dense_batch(a, b, c, low, high, deltas, sdmin, sdmax, want_X=False, active=None, squared=False):
     """compute_reachable_sets(sdmin, sdmax) on dense rows (see :func:`solve_dense_batch`) -> L [B, N+1, 2] (and the feasible
     sets X it computes on the way with ``want_X``)."""
     _prepare(a)
-    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, active=active)
+    p, keep = _capi.make_dense_problem(a, b, c, low, high, deltas, active=active, squared=squared)
     sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, a)
     sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, a)
     L = _empty(a, (p.B, p.N + 1, 2))
@@ -237,11 +238,11 @@ def feasible_sets_dense_batch(a, b, c, low, high, deltas, active=None):
     return X
 
 
-def reachable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpolation=True, want_X=False):
+def reachable_sets_batch(coef, breaks, grid, vlim, alim, sdmin, sdmax, interpolation=True, want_X=False, squared=False):
     """compute_reachable_sets(sdmin, sdmax) for B trajectories -> L[B,N+1,2] (and the feasible sets
     X[B,N+1,2] it computes on the way with ``want_X``)."""
     _prepare(coef)
-    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation)
+    p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation, squared=squared)
     sdmin = _capi.per_traj_vector("sdmin", sdmin, p.B, coef)
     sdmax = _capi.per_traj_vector("sdmax", sdmax, p.B, coef)
     L = _empty(coef, (p.B, p.N + 1, 2))

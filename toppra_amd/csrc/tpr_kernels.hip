@@ -328,8 +328,13 @@ int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
 // status are requested; the strict mode stays with family 2.
 bool cert_supported(const tpr::BatchArgs &A) {
     return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= ((A.flags & TPR_SOUND_CERTIFICATES) ? 8 : TPR_CERT_MAX_DOF) &&
-           !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 &&
+           !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 && !A.active &&
            (A.backward_only || (A.sd2 && A.u && A.status));
+}
+
+// Return codes of the per-dof translation units of family 3: 0, or a negative "this instantiation does not exist".
+int cert_tu_rc(int rc) {
+    return rc < 0 ? fail(TPR_E_UNSUPPORTED, "kernel family 3: this combination of dof / discretisation / certificate mode is not instantiated") : rc;
 }
 
 // Kernel family 3 lives in its own translation units, one per dof (tpr_cert_tu.hip; build.py compiles them in parallel).
@@ -338,38 +343,38 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
                      A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status, A.sd_end_hi, A.backward_only};
     switch (A.d) {
 #ifndef TPR_CERT_DEV  // development builds instantiate 7 dof only
-        case 1: return tpr_tu_cert_launch_1(&G, stream);
-        case 2: return tpr_tu_cert_launch_2(&G, stream);
-        case 3: return tpr_tu_cert_launch_3(&G, stream);
-        case 4: return tpr_tu_cert_launch_4(&G, stream);
-        case 5: return tpr_tu_cert_launch_5(&G, stream);
-        case 6: return tpr_tu_cert_launch_6(&G, stream);
-        case 8: return tpr_tu_cert_launch_8(&G, stream);
+        case 1: return cert_tu_rc(tpr_tu_cert_launch_1(&G, stream));
+        case 2: return cert_tu_rc(tpr_tu_cert_launch_2(&G, stream));
+        case 3: return cert_tu_rc(tpr_tu_cert_launch_3(&G, stream));
+        case 4: return cert_tu_rc(tpr_tu_cert_launch_4(&G, stream));
+        case 5: return cert_tu_rc(tpr_tu_cert_launch_5(&G, stream));
+        case 6: return cert_tu_rc(tpr_tu_cert_launch_6(&G, stream));
+        case 8: return cert_tu_rc(tpr_tu_cert_launch_8(&G, stream));
 #if TPR_CERT_MAX_DOF >= 9
-        case 9: return tpr_tu_cert_launch_9(&G, stream);
+        case 9: return cert_tu_rc(tpr_tu_cert_launch_9(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 10
-        case 10: return tpr_tu_cert_launch_10(&G, stream);
+        case 10: return cert_tu_rc(tpr_tu_cert_launch_10(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 11
-        case 11: return tpr_tu_cert_launch_11(&G, stream);
+        case 11: return cert_tu_rc(tpr_tu_cert_launch_11(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 12
-        case 12: return tpr_tu_cert_launch_12(&G, stream);
+        case 12: return cert_tu_rc(tpr_tu_cert_launch_12(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 13
-        case 13: return tpr_tu_cert_launch_13(&G, stream);
+        case 13: return cert_tu_rc(tpr_tu_cert_launch_13(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 14
-        case 14: return tpr_tu_cert_launch_14(&G, stream);
+        case 14: return cert_tu_rc(tpr_tu_cert_launch_14(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 15
-        case 15: return tpr_tu_cert_launch_15(&G, stream);
+        case 15: return cert_tu_rc(tpr_tu_cert_launch_15(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 16
-        case 16: return tpr_tu_cert_launch_16(&G, stream);
+        case 16: return cert_tu_rc(tpr_tu_cert_launch_16(&G, stream));
 #endif
-        case 7: return tpr_tu_cert_launch_7(&G, stream);
+        case 7: return cert_tu_rc(tpr_tu_cert_launch_7(&G, stream));
 #else
         case TPR_SINGLE_TU_D: return TPR_TU_CAT3(tpr_tu_cert_launch_, TPR_SINGLE_TU_D)(&G, stream);
 #endif
@@ -388,38 +393,38 @@ int launch_cert_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream)
                      A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status};
     switch (A.d) {
 #ifndef TPR_CERT_DEV
-        case 1: return tpr_tu_cert_feasible_launch_1(&G, X, stream);
-        case 2: return tpr_tu_cert_feasible_launch_2(&G, X, stream);
-        case 3: return tpr_tu_cert_feasible_launch_3(&G, X, stream);
-        case 4: return tpr_tu_cert_feasible_launch_4(&G, X, stream);
-        case 5: return tpr_tu_cert_feasible_launch_5(&G, X, stream);
-        case 6: return tpr_tu_cert_feasible_launch_6(&G, X, stream);
-        case 8: return tpr_tu_cert_feasible_launch_8(&G, X, stream);
+        case 1: return cert_tu_rc(tpr_tu_cert_feasible_launch_1(&G, X, stream));
+        case 2: return cert_tu_rc(tpr_tu_cert_feasible_launch_2(&G, X, stream));
+        case 3: return cert_tu_rc(tpr_tu_cert_feasible_launch_3(&G, X, stream));
+        case 4: return cert_tu_rc(tpr_tu_cert_feasible_launch_4(&G, X, stream));
+        case 5: return cert_tu_rc(tpr_tu_cert_feasible_launch_5(&G, X, stream));
+        case 6: return cert_tu_rc(tpr_tu_cert_feasible_launch_6(&G, X, stream));
+        case 8: return cert_tu_rc(tpr_tu_cert_feasible_launch_8(&G, X, stream));
 #if TPR_CERT_MAX_DOF >= 9
-        case 9: return tpr_tu_cert_feasible_launch_9(&G, X, stream);
+        case 9: return cert_tu_rc(tpr_tu_cert_feasible_launch_9(&G, X, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 10
-        case 10: return tpr_tu_cert_feasible_launch_10(&G, X, stream);
+        case 10: return cert_tu_rc(tpr_tu_cert_feasible_launch_10(&G, X, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 11
-        case 11: return tpr_tu_cert_feasible_launch_11(&G, X, stream);
+        case 11: return cert_tu_rc(tpr_tu_cert_feasible_launch_11(&G, X, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 12
-        case 12: return tpr_tu_cert_feasible_launch_12(&G, X, stream);
+        case 12: return cert_tu_rc(tpr_tu_cert_feasible_launch_12(&G, X, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 13
-        case 13: return tpr_tu_cert_feasible_launch_13(&G, X, stream);
+        case 13: return cert_tu_rc(tpr_tu_cert_feasible_launch_13(&G, X, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 14
-        case 14: return tpr_tu_cert_feasible_launch_14(&G, X, stream);
+        case 14: return cert_tu_rc(tpr_tu_cert_feasible_launch_14(&G, X, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 15
-        case 15: return tpr_tu_cert_feasible_launch_15(&G, X, stream);
+        case 15: return cert_tu_rc(tpr_tu_cert_feasible_launch_15(&G, X, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 16
-        case 16: return tpr_tu_cert_feasible_launch_16(&G, X, stream);
+        case 16: return cert_tu_rc(tpr_tu_cert_feasible_launch_16(&G, X, stream));
 #endif
-        case 7: return tpr_tu_cert_feasible_launch_7(&G, X, stream);
+        case 7: return cert_tu_rc(tpr_tu_cert_feasible_launch_7(&G, X, stream));
 #else
         case TPR_SINGLE_TU_D: return TPR_TU_CAT3(tpr_tu_cert_feasible_launch_, TPR_SINGLE_TU_D)(&G, X, stream);
 #endif
@@ -433,38 +438,38 @@ int launch_cert_sd(const tpr::BatchArgs &A, double *xf, double *uf, double *xl, 
                      A.sd_start, A.sd_end, A.sd2, nullptr, A.u, A.K, A.status, nullptr, 0, xf, uf, xl, ul};
     switch (A.d) {
 #ifndef TPR_CERT_DEV
-        case 1: return tpr_tu_cert_sd_launch_1(&G, stream);
-        case 2: return tpr_tu_cert_sd_launch_2(&G, stream);
-        case 3: return tpr_tu_cert_sd_launch_3(&G, stream);
-        case 4: return tpr_tu_cert_sd_launch_4(&G, stream);
-        case 5: return tpr_tu_cert_sd_launch_5(&G, stream);
-        case 6: return tpr_tu_cert_sd_launch_6(&G, stream);
-        case 8: return tpr_tu_cert_sd_launch_8(&G, stream);
+        case 1: return cert_tu_rc(tpr_tu_cert_sd_launch_1(&G, stream));
+        case 2: return cert_tu_rc(tpr_tu_cert_sd_launch_2(&G, stream));
+        case 3: return cert_tu_rc(tpr_tu_cert_sd_launch_3(&G, stream));
+        case 4: return cert_tu_rc(tpr_tu_cert_sd_launch_4(&G, stream));
+        case 5: return cert_tu_rc(tpr_tu_cert_sd_launch_5(&G, stream));
+        case 6: return cert_tu_rc(tpr_tu_cert_sd_launch_6(&G, stream));
+        case 8: return cert_tu_rc(tpr_tu_cert_sd_launch_8(&G, stream));
 #if TPR_CERT_MAX_DOF >= 9
-        case 9: return tpr_tu_cert_sd_launch_9(&G, stream);
+        case 9: return cert_tu_rc(tpr_tu_cert_sd_launch_9(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 10
-        case 10: return tpr_tu_cert_sd_launch_10(&G, stream);
+        case 10: return cert_tu_rc(tpr_tu_cert_sd_launch_10(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 11
-        case 11: return tpr_tu_cert_sd_launch_11(&G, stream);
+        case 11: return cert_tu_rc(tpr_tu_cert_sd_launch_11(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 12
-        case 12: return tpr_tu_cert_sd_launch_12(&G, stream);
+        case 12: return cert_tu_rc(tpr_tu_cert_sd_launch_12(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 13
-        case 13: return tpr_tu_cert_sd_launch_13(&G, stream);
+        case 13: return cert_tu_rc(tpr_tu_cert_sd_launch_13(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 14
-        case 14: return tpr_tu_cert_sd_launch_14(&G, stream);
+        case 14: return cert_tu_rc(tpr_tu_cert_sd_launch_14(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 15
-        case 15: return tpr_tu_cert_sd_launch_15(&G, stream);
+        case 15: return cert_tu_rc(tpr_tu_cert_sd_launch_15(&G, stream));
 #endif
 #if TPR_CERT_MAX_DOF >= 16
-        case 16: return tpr_tu_cert_sd_launch_16(&G, stream);
+        case 16: return cert_tu_rc(tpr_tu_cert_sd_launch_16(&G, stream));
 #endif
-        case 7: return tpr_tu_cert_sd_launch_7(&G, stream);
+        case 7: return cert_tu_rc(tpr_tu_cert_sd_launch_7(&G, stream));
 #else
         case TPR_SINGLE_TU_D: return TPR_TU_CAT3(tpr_tu_cert_sd_launch_, TPR_SINGLE_TU_D)(&G, stream);
 #endif
@@ -551,7 +556,9 @@ int launch_wave(const tpr::BatchArgs &A, hipStream_t stream) {
 // Kernel family of a solve (tpr_problem.variant 0 = auto).
 int pick_variant(int requested, const tpr::BatchArgs &A) {
     if (requested != 0) return requested;
-    if (A.active && wave_supported(A)) return 4;  // the wrapper object's warm-start state in / out: family 4 maintains it
+    // the wrapper object's warm-start state in / out: family 4 maintains it, and so does the generic lane kernel (family 1)
+    // for what family 4 cannot take (N > 1480); families 2 and 3 neither read nor update it
+    if (A.active) return wave_supported(A) ? 4 : 1;
     // Batches that cannot fill the chip are bound by the latency of a trajectory's 3N sequential stage LPs: one
     // wave per trajectory (family 4).  Family 3 finishes up to 65536 trajectories (one wave per SIMD) in one
     // fixed-latency round, which beats family 2's throughput from about a quarter of that batch upward
@@ -566,6 +573,8 @@ int pick_variant(int requested, const tpr::BatchArgs &A) {
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
     if (A.B == 0) return TPR_E_OK;
     const int variant = pick_variant(p->variant, A);
+    if (A.active && (variant == 2 || variant == 3))
+        return fail(TPR_E_UNSUPPORTED, "tpr_problem.active (warm-start state in / out) is maintained by kernel families 4 and 1 only: leave variant at 0");
     switch (variant) {
         case 4: {
             if (!wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables (N <= 1480)");
@@ -612,8 +621,11 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
         }
         case 1: {
             const int block = 64;
-            hipLaunchKernelGGL(tpr::lane_solve_kernel, dim3((A.B + block - 1) / block), dim3(block), 0,
-                               stream, A);
+            if (A.backward_only)  // compute_controllable_sets on its own
+                hipLaunchKernelGGL(tpr::lane_controllable_kernel, dim3((A.B + block - 1) / block), dim3(block), 0, stream, A,
+                                   A.sd_end, A.sd_end_hi ? A.sd_end_hi : A.sd_end);
+            else
+                hipLaunchKernelGGL(tpr::lane_solve_kernel, dim3((A.B + block - 1) / block), dim3(block), 0, stream, A);
             return TPR_E_OK;
         }
         default:
@@ -687,7 +699,15 @@ extern "C" {
 
 const char *tpr_last_error(void) { return g_err.c_str(); }
 
-const char *tpr_version(void) { return "toppra_hip 0.1 (gfx950)"; }
+const char *tpr_version(void) { return "toppra_hip 0.2 (gfx950)"; }
+// ABI guard: the structures of this header grow at the END from version to version (0.2: tpr_problem.active); a binding built
+// against an older header would pass a shorter structure, so it compares these sizes with its own before the first call.
+int tpr_abi_sizes(int32_t *problem_bytes, int32_t *result_bytes, int32_t *dense_problem_bytes) {
+    if (problem_bytes) *problem_bytes = (int32_t)sizeof(tpr_problem);
+    if (result_bytes) *result_bytes = (int32_t)sizeof(tpr_result);
+    if (dense_problem_bytes) *dense_problem_bytes = (int32_t)sizeof(tpr_dense_problem);
+    return 2;  // ABI revision
+}
 
 int tpr_device_count(void) {
     int n = 0;
@@ -804,16 +824,15 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
     double *ws = nullptr;
     int32_t *wstatus = nullptr, *wlist = nullptr;
     const size_t per = 2 * (N + 1) + 2 * N;
-    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * (per + (dalpha ? 0 : 1)) * sizeof(double) + 8, stream);
-    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&wlist), (B + 2) * sizeof(int32_t), stream);
+    // (every allocation joins S.owned as soon as it exists: an early return must not leak the ones before it)
+    if (S.err == hipSuccess) { S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * (per + (dalpha ? 0 : 1)) * sizeof(double) + 8, stream); if (S.err == hipSuccess) S.owned.push_back(ws); }
+    if (S.err == hipSuccess) { S.err = hipMallocAsync(reinterpret_cast<void **>(&wlist), (B + 2) * sizeof(int32_t), stream); if (S.err == hipSuccess) S.owned.push_back(wlist); }
     if (S.err == hipSuccess && !A.status) {
         S.err = hipMallocAsync(reinterpret_cast<void **>(&wstatus), B * sizeof(int32_t) + 4, stream);
+        if (S.err == hipSuccess) S.owned.push_back(wstatus);
         A.status = wstatus;
     }
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    S.owned.push_back(ws);
-    S.owned.push_back(wlist);
-    if (wstatus) S.owned.push_back(wstatus);
     if (!dalpha) dalpha = ws + B * per;
     if (A.B > 0) {
         double *xf = ws, *uf = ws + B * (N + 1), *xl = ws + B * (2 * N + 1), *ul = ws + B * (3 * N + 2);
@@ -977,7 +996,7 @@ static __global__ void __launch_bounds__(64) lane_dense_reachable_kernel(DenseAr
         Xb[2 * i] = lo; Xb[2 * i + 1] = hi;
     }
     for (int i = 0; i <= N; ++i) { Lb[2 * i] = 0.0; Lb[2 * i + 1] = 0.0; }
-    double l0 = sdmin[b] * sdmin[b], l1 = sdmax[b] * sdmax[b];
+    double l0 = boundary_x(A.flags, sdmin[b]), l1 = boundary_x(A.flags, sdmax[b]);
     Lb[0] = l0; Lb[1] = l1;
     for (int i = 0; i < N; ++i) {
         const double delta = deltas[i];
@@ -1060,16 +1079,15 @@ int tpr_solve_desired_duration_dense_batch(const tpr_dense_problem *p, const dou
     double *ws = nullptr;
     int32_t *wstatus = nullptr, *wlist = nullptr;
     const size_t per = 2 * (N + 1) + 2 * N;
-    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * (per + (dalpha ? 0 : 1)) * sizeof(double) + 8, stream);
-    if (S.err == hipSuccess) S.err = hipMallocAsync(reinterpret_cast<void **>(&wlist), (B + 2) * sizeof(int32_t), stream);
+    // (every allocation joins S.owned as soon as it exists: an early return must not leak the ones before it)
+    if (S.err == hipSuccess) { S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * (per + (dalpha ? 0 : 1)) * sizeof(double) + 8, stream); if (S.err == hipSuccess) S.owned.push_back(ws); }
+    if (S.err == hipSuccess) { S.err = hipMallocAsync(reinterpret_cast<void **>(&wlist), (B + 2) * sizeof(int32_t), stream); if (S.err == hipSuccess) S.owned.push_back(wlist); }
     if (S.err == hipSuccess && !A.status) {
         S.err = hipMallocAsync(reinterpret_cast<void **>(&wstatus), B * sizeof(int32_t) + 4, stream);
+        if (S.err == hipSuccess) S.owned.push_back(wstatus);
         A.status = wstatus;
     }
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    S.owned.push_back(ws);
-    S.owned.push_back(wlist);
-    if (wstatus) S.owned.push_back(wstatus);
     if (!dalpha) dalpha = ws + B * per;
     if (A.B > 0) {
         A.sd_xf = ws; A.sd_uf = ws + B * (N + 1); A.sd_xl = ws + B * (2 * N + 1); A.sd_ul = ws + B * (3 * N + 2);
@@ -1197,7 +1215,11 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
         if (want == 3 && !cert_feasible_supported(A))
             return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 13 (8 with sound certificates), no strict mode, no warm-start state");
         if (want == 4 && !wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables");
-        if (want == 4 || (want == 0 && wave_auto)) {
+        if (A.active && (want == 2 || want == 3))
+            return fail(TPR_E_UNSUPPORTED, "tpr_problem.active (warm-start state in / out) is maintained by kernel families 4 and 1 only: leave variant at 0");
+        if (A.active && want == 0 && !wave_supported(A)) {  // N > 1480: the generic lane kernel carries the state
+            hipLaunchKernelGGL(tpr::lane_feasible_kernel, dim3((A.B + 63) / 64), dim3(64), 0, stream, A, dX);
+        } else if (want == 4 || (want == 0 && wave_auto)) {
             // one trajectory per wave: a handful of trajectories (latency), 17..32 dof, or the wrapper object's
             // warm-start state in / out
             A.feasible_X = dX;

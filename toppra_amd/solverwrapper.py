@@ -130,12 +130,12 @@ class hipSeidelWrapper(SolverWrapper):
         return batch.feasible_sets_batch(*self._args(), self._interp, active=self._active)[0]
 
     def reachable_sets(self, sdmin, sdmax):
-        L, X = batch.reachable_sets_batch(*self._args(), np.array([sdmin], dtype=np.float64),
-                                          np.array([sdmax], dtype=np.float64), self._interp, want_X=True)
+        L, X = batch.reachable_sets_batch(*self._args(), np.array([sdmin ** 2], dtype=np.float64),
+                                          np.array([sdmax ** 2], dtype=np.float64), self._interp, want_X=True, squared=True)
         return L[0], X[0]
 
     def parameterization(self, sd_start, sd_end):
-        """One compute_parameterization: sd2, sd, u, K [views of per-instance buffers], status.  A single
+        """One compute_parameterization: sd2, sd, u, K [copies of the per-instance result buffers], status.  A single
         trajectory is pure call latency, so the problem description, the result buffers and the ctypes
         arguments are built once per instance; a call writes the two boundary velocities and makes one
         library call (which takes its small-host-call path: csrc/tpr_kernels.hip)."""
@@ -158,14 +158,14 @@ class hipSeidelWrapper(SolverWrapper):
         rc = fn(pref, rref, None)
         if rc != 0:
             _capi.check(rc)
-        res = dict(views)
+        res = {k: v.copy() for k, v in views.items()}  # (the buffers are reused by the next call: never hand out views)
         res["status"] = int(status[0])
         return res
 
     def parameterization_sd(self, sd_start, sd_end, desired_duration, atol=1e-5):
         out = batch.solve_desired_duration_batch(*self._args(), desired_duration,
-                                                 np.array([sd_start], dtype=np.float64),
-                                                 np.array([sd_end], dtype=np.float64), atol)
+                                                 np.array([sd_start ** 2], dtype=np.float64),
+                                                 np.array([sd_end ** 2], dtype=np.float64), atol, squared=True)
         return {k: v[0] for k, v in out.items()}
 
     # -- single-LP compatibility entry ---------------------------------------------------------
@@ -310,13 +310,15 @@ class hipDenseSeidelWrapper(SolverWrapper):
         return var
 
     def reachable_sets(self, sdmin, sdmax):
-        L, X = batch.reachable_sets_dense_batch(*self._rows, np.array([sdmin], dtype=np.float64),
-                                                np.array([sdmax], dtype=np.float64), want_X=True, active=self._active)
+        L, X = batch.reachable_sets_dense_batch(*self._rows, np.array([sdmin ** 2], dtype=np.float64),
+                                                np.array([sdmax ** 2], dtype=np.float64), want_X=True, active=self._active,
+                                                squared=True)
         return L[0], X[0]
 
     def parameterization_sd(self, sd_start, sd_end, desired_duration, atol=1e-5):
-        out = batch.solve_desired_duration_dense_batch(*self._rows, desired_duration, np.array([sd_start], dtype=np.float64),
-                                                       np.array([sd_end], dtype=np.float64), atol, active=self._active)
+        out = batch.solve_desired_duration_dense_batch(*self._rows, desired_duration, np.array([sd_start ** 2], dtype=np.float64),
+                                                       np.array([sd_end ** 2], dtype=np.float64), atol, active=self._active,
+                                                       squared=True)
         return {k: v[0] for k, v in out.items()}
 
 
