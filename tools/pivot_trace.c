@@ -82,12 +82,33 @@ static int emulate_ok(int jfirst) {
     return 1;
 }
 
+static char cold_sigs[256][160]; static long cold_cnt[256]; static int cold_nsig = 0;
 static void tr_end(int result, const int *active) {
     n_lp++;
     if (!(T.v[1] > 0)) return;  /* upper-bound LP of the backward scan: v = (-1e-9, 1) */
     n_upper++;
     const int warm_ok = T.warm[0] >= 0 && T.warm[1] >= 0 && T.warm[0] < T.nrows && T.warm[1] < T.nrows && T.warm[0] != T.warm[1];
-    if (!warm_ok) return;
+    if (!warm_ok) {
+        /* cold order (identity): signature of the run */
+        char sig[160]; int n = 0;
+        n += sprintf(sig + n, "cold(%ld,%ld) res=%d: ", T.warm[0], T.warm[1], result);
+        for (int j = 0; j < T.np && n < 140; ++j) {
+            const struct tr_pivot *p = &T.p[j];
+            const double v1d = -T.b[p->row] * T.v[0] + T.a[p->row] * T.v[1];
+            const int pick_min = fabs(v1d) < 1e-10 || v1d < 0;
+            const int act = pick_min ? p->amin : p->amax;
+            long lim = act < (int)p->k ? T.index_map[act] : -1 - (act - (int)p->k);
+            char rc = p->row == 0 ? '0' : (p->row == 1 ? '1' : 'A');
+            char lc = lim < 0 ? (lim == -4 ? 'H' : (lim == -3 ? 'L' : 'B')) : (lim == 0 ? '0' : (lim == 1 ? '1' : 'A'));
+            sig[n++] = rc; sig[n++] = lc; sig[n++] = ' ';
+        }
+        sig[n] = 0;
+        int f = -1;
+        for (int q = 0; q < cold_nsig; ++q) if (!strcmp(cold_sigs[q], sig)) f = q;
+        if (f < 0 && cold_nsig < 256) { f = cold_nsig++; strcpy(cold_sigs[f], sig); }
+        if (f >= 0) cold_cnt[f]++;
+        return;
+    }
     n_upper_warm++;
     if (!result) { n_infeasible++; return; }
     const int kept = (active[0] == T.warm[0] && active[1] == T.warm[1]) || (active[0] == T.warm[1] && active[1] == T.warm[0]);
@@ -202,6 +223,7 @@ int main(int argc, char **argv) {
         printf("      loose rows at z_w:"); for (int j = 0; j < 16; ++j) printf(" %ld", loose_hist[c][j]); printf("\n");
         printf("      violated at z_w:  "); for (int j = 0; j < 16; ++j) printf(" %ld", viol_hist[c][j]); printf("\n");
     }
+    if (getenv("TRACE_COLD")) for (int q = 0; q < cold_nsig; ++q) printf("%8ld  %s\n", cold_cnt[q], cold_sigs[q]);
     printf("pivots per moved LP:"); for (int j = 0; j < 32; ++j) if (extra_hist[j]) printf(" %d:%ld", j, extra_hist[j]); printf("\n");
     printf("first violated row in order == most violated: %ld\n", first_is_most);
     printf("smallest relative 1-D segment after the warm pair: %.3g; below 1e-j:", min_rel_seg);

@@ -20,6 +20,7 @@ def main():
     N = int(sys.argv[3]) if len(sys.argv) > 3 else 200
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else 20240924
     data = batch.make_synthetic_batch(B, d, N, seed=seed)
+    data["vlim"] = data["vlim"] * float(os.environ.get("VSCALE", "1"))
     exe = "/tmp/pivot_trace"
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-o", exe,
                            os.path.join(ROOT, "tools", "pivot_trace.c"), "-lm"])

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtoppra_hip.so")
 SOURCES = ["tpr_kernels.hip", "tpr_cert_tu.hip", "tpr_robust_tu.hip", "tpr_dense_tu.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-Wno-unused-variable"]
 
 
 def hipcc():

@@ -26,7 +26,7 @@
 // instantiation bit-exact, as are the neighbouring dofs, Collocation, and every fast instantiation (DESIGN.md section
 // 3.2).  Sound requests above 8 dof are served by the rows-across-lanes kernels, whose sound mode is bit-exact there.
 // -2 = not instantiated.
-constexpr bool kSoundHere = TPR_TU_D <= 8;
+constexpr bool kSoundHere = true;  // round 4: the trace-following sound certificates, every dof of this family
 
 #define TPR_TU_CAT2(a, b) a##b
 #define TPR_TU_CAT(a, b) TPR_TU_CAT2(a, b)

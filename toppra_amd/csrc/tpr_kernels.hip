@@ -327,7 +327,7 @@ int dispatch_sd_forward(int d, const tpr::SdArgs &A, hipStream_t stream) {
 // The certified lane kernel (family 3) serves the same constraint set up to 8 dof when sd2, u and
 // status are requested; the strict mode stays with family 2.
 bool cert_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= ((A.flags & TPR_SOUND_CERTIFICATES) ? 8 : TPR_CERT_MAX_DOF) &&
+    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= TPR_CERT_MAX_DOF &&
            !(A.flags & TPR_STRICT_SEIDEL) && A.N >= 1 && !A.active &&
            (A.backward_only || (A.sd2 && A.u && A.status));
 }
@@ -384,7 +384,7 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
 
 // compute_feasible_sets on the certified lane design: the constraint sets and dofs of family 3, fresh warm-start state
 bool cert_feasible_supported(const tpr::BatchArgs &A) {
-    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= ((A.flags & TPR_SOUND_CERTIFICATES) ? 8 : TPR_CERT_MAX_DOF) &&
+    return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= TPR_CERT_MAX_DOF &&
            !(A.flags & TPR_STRICT_SEIDEL) && !A.active;
 }
 
