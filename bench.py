@@ -600,7 +600,7 @@ def main():
     # secondary (single-GPU kernel times, not the headline): the reference's full Seidel iteration for
     # every LP (TPR_STRICT_SEIDEL, kernel family 2) and family 2 with its certified shortcuts; the
     # default path must return the same bits as the full iteration
-    strict_ms = family2_ms = same_bits = sound_ms = sound_same = None
+    strict_ms = family2_ms = same_bits = None
     if not args.no_secondary and world == 1:
         reps = max(2, args.kernel_reps // 2)
         full = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], strict=True)
@@ -610,13 +610,6 @@ def main():
                                          reps=reps, strict=True)
         family2_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], full,
                                           reps=reps, variant=2)
-        # the sound certificate mode of the default kernel (TPR_SOUND_CERTIFICATES)
-        snd = tb.solve_batch(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], sound=True, variant=args.variant)
-        sound_same = all(bool(torch.equal(torch.nan_to_num(snd[k], nan=-7.0), torch.nan_to_num(full[k], nan=-7.0)))
-                         for k in ("sd2", "u", "K")) and bool(torch.equal(snd["status"], full["status"]))
-        sound_ms = tb.solve_batch_timed(dv["coef"], dv["breaks"], dv["grid"], dv["vlim"], dv["alim"], snd,
-                                        reps=reps, variant=args.variant, sound=True)
-        del snd
     ok_frac = float((out["status"] == 0).double().mean().item())
 
     # multi-GPU: what each rank's kernel took and what the gather costs on its own (outside the timed region),
@@ -678,14 +671,9 @@ def main():
                 "unit": "trajectories/s",
                 "default_path_returns_identical_bits": same_bits,
             },
-            "sound_certificates": {
-                "note": "TPR_SOUND_CERTIFICATES: the default kernel certifying a MOVED active pair only where the reference's own "
-                        "pivot sequence is predictable (everything else through the full iteration); the default (fast) mode "
-                        "returns the LP's optimum on a stage where the reference itself fails on a 1e-14 sliver of an "
-                        "intermediate pivot -- 1 in 204800 adversarial trajectories, none in natural batches (DESIGN.md 3.1)",
-                "kernel_ms": sound_ms, "value_per_gpu": (B / sound_ms * 1e3) if sound_ms else None, "unit": "trajectories/s",
-                "identical_bits_to_full_iteration": sound_same,
-            },
+            "certificates": "trace-following (sound) certificates are the only mode since round 4: a stage LP is answered from a "
+                            "certificate only where the reference's whole pivot sequence is predictable (DESIGN.md 3.1); "
+                            "TPR_SOUND_CERTIFICATES is accepted and ignored",
             "family2_rows_across_lanes": {
                 "note": "kernel family 2 (8 lanes per trajectory) with its certified shortcuts; serves d > 8 and the "
                         "strict mode; single-GPU kernel time only",

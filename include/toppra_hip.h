@@ -53,25 +53,19 @@ extern "C" {
  * Honoured by tpr_solve_batch, tpr_controllable_sets_batch, tpr_solve_desired_duration_batch.                  */
 #define TPR_BOUNDARY_SQUARED 256
 /* Force every stage LP through the full Seidel iteration (served by the rows-across-lanes kernels).
- * By default the fast kernels answer a backward LP from a verified optimal vertex -- found as "x on its
- * box bound, u on the tightest row" (lower bound) or as the previous stage's active pair, if need be
- * after a short simplex walk (upper bound), and checked with margins 1e3..1e4 above the solver's
- * tolerances -- by evaluating the reference's own last-pivot formulas for it; what does not verify
- * runs the full iteration.  Both give the same bits (cross-checked on ~1e8 stage LPs,
- * tests/test_gpu_fullsize.py); this flag exists for A/B testing and for callers who want the
+ * By default the throughput kernels answer a backward LP from a certificate -- the reference's own pivot trace followed
+ * with margins far above the solver's tolerances, the final vertex verified against every row, and the reference's
+ * last-pivot formulas evaluated for it; what is not predictable runs the full iteration.  Both give the same bits
+ * (tests/test_gpu_fullsize.py on the GPU, tests/test_host_cert.py on the CPU: the certificate source against the
+ * restatement of the reference, stage LP by stage LP); this flag exists for A/B testing and for callers who want the
  * iteration itself replicated.                                                                     */
 #define TPR_STRICT_SEIDEL 128
-/* Certificates of the throughput kernels (families 2, 3) in SOUND mode: a stage LP whose active pair MOVED against
- * the previous stage is answered from a certificate only where the reference's own pivot sequence is predictable up
- * to its last pivot (one violated row at a warm vertex that is still optimal for its own rows, the new partner
- * inside that row's 1-D problem); every other moved pair runs the full iteration.  The default (fast) mode certifies
- * moved pairs on conditions that bound the reference's LAST pivot only; an earlier pivot of the reference can still
- * end ITS run with "infeasible" on an LP with a well separated optimum -- three constraint rows through one point to
- * 1e-10, a sliver of 1e-14 (tests/test_gpu_fullsize.py::test_concurrent_rows_and_sliver_pivots_are_bit_exact:
- * 1 in 1.5e5 trajectories of an adversarial family, ~1e-5 expected events per 65536 x 200 natural batch, none
- * observed in 4e9 stage LPs) -- and the fast mode then returns the LP's optimum where the reference reports failure.
- * Kernel family 4 (the latency kernel, which serves the drop-in class) is always sound.  Above 8 dof the flag is served
- * by the rows-across-lanes kernels.  Cost at the headline shape: see DESIGN.md section 3.1.                                                                                        */
+/* Accepted and ignored since round 4: every kernel family certifies a stage LP only where the reference's WHOLE pivot
+ * sequence is predictable (rounds 2-3 had a faster default that bounded the reference's last pivot only and could return
+ * an LP's optimum where an earlier pivot of the reference ends its run with "infeasible" -- a 1e-14 sliver, 1 in 1.5e5
+ * trajectories of an adversarial family).  Family 3 follows the trace at lane level (prologue pivots, the slide along the
+ * limiting row as prefix records: DESIGN.md section 3.1), family 2 certifies a moved pair after one predictable pivot,
+ * family 4 the kept pair only; everything else runs the reference's iteration.                                       */
 #define TPR_SOUND_CERTIFICATES 512
 
 /* per-trajectory status == ParameterizationReturnCode (algorithm/algorithm.py:49-62) */

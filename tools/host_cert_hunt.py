@@ -35,12 +35,12 @@ def build(force=False):
     return EXE
 
 
-def run(coef, breaks, grid, vlim, alim, sd_end=None, flags=FLAG_VEL | FLAG_ACC | FLAG_INTERP, mode=0, verbose=False):
+def run(coef, breaks, grid, vlim, alim, sd_end=None, flags=FLAG_VEL | FLAG_ACC | FLAG_INTERP, mode=0, verbose=False, legacy=False):
     build()
     B, _, nseg, d = coef.shape
     N = len(grid) - 1
     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
-        np.array([B, d, nseg, N, flags, mode, 0 if sd_end is None else 1, 0], dtype=np.int32).tofile(f)
+        np.array([B, d, nseg, N, flags, mode, 0 if sd_end is None else 1, 1 if legacy else 0], dtype=np.int32).tofile(f)
         for arr in (coef, breaks, grid, vlim, alim):
             np.ascontiguousarray(arr, dtype=np.float64).tofile(f)
         if sd_end is not None:
@@ -98,7 +98,7 @@ def sliver_family(B, d, N, seed):
 
 def workloads(family, B, seed):
     rng = np.random.default_rng(900 + seed)
-    shapes = [(7, 200), (3, 60), (6, 120), (4, 80), (8, 64), (5, 100), (2, 40), (1, 50)]
+    shapes = [(7, 200), (3, 60), (6, 120), (4, 80), (8, 64), (5, 100), (2, 40), (1, 50), (9, 50), (12, 40), (13, 30)]
     d, N = shapes[seed % len(shapes)]
     data = batch.make_synthetic_batch(B, d, N, seed=5000 + 17 * seed)
     coef, breaks, grid, vlim, alim = data["coef"], data["breaks"], data["grid"], data["vlim"], data["alim"]
@@ -125,6 +125,25 @@ def workloads(family, B, seed):
             coef[:, :, :, k1] = sc * coef[:, :, :, k0] * (1.0 + tilt * rng.standard_normal((B, 4, coef.shape[2])))
             alim = alim.copy()
             alim[:, k1] = alim[:, k0] * sc[:, 0] * (1.0 + 10.0 ** rng.uniform(-12, -3, size=(B, 1)))
+    elif family == "lower_ties":
+        # two rows whose bounds on u at x = low1 (= 0 for these rest-to-rest problems: -c / a) agree to 1e-8 .. 1e-15 at one
+        # stage: a near-tie between a prefix record of the lower-bound LP's cold run and the row visited next
+        from oracle import oracle as orc
+        alim = alim.copy()
+        j = rng.integers(1, N - 1, size=B)
+        for b in range(B):
+            q1, q2 = orc.path_eval(coef[b], breaks, float(grid[j[b]]))
+            k, m = rng.choice(d, size=2, replace=False) if d >= 2 else (0, 0)
+            if d < 2 or q1[k] == 0 or q1[m] == 0:
+                continue
+            eps = 10.0 ** rng.uniform(-15, -8) * rng.choice([-1.0, 1.0])
+            # bound of joint k: amax_k / |q1_k| (its + or - row, whichever has a > 0); make joint m's bound equal to it
+            t_k = (alim[b, k, 1] if q1[k] > 0 else -alim[b, k, 0]) / abs(q1[k])
+            val = t_k * abs(q1[m]) * (1.0 + eps)
+            if q1[m] > 0:
+                alim[b, m, 1] = val
+            else:
+                alim[b, m, 0] = -val
     elif family == "feasible":
         mode = 1
         if seed % 2:
@@ -134,16 +153,17 @@ def workloads(family, B, seed):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    opts = dict(a[2:].split("=") for a in sys.argv[1:] if a.startswith("--") and "=" in a)
+    opts = dict((a[2:].split("=") + ["1"])[:2] for a in sys.argv[1:] if a.startswith("--"))
     rounds, B, start = int(opts.get("rounds", 1)), int(opts.get("B", 256)), int(opts.get("start", 0))
+    legacy = "legacy" in opts
     fams = args or ["natural", "scaled", "tight", "boundary", "collocation", "acc_only", "sliver", "parallel", "feasible"]
     build(force=start == 0)
     bad = 0
     for r in range(start, start + rounds):
         for fam in fams:
-            for seed in range(8 * r, 8 * r + 8):
+            for seed in range(11 * r, 11 * r + 11):
                 (coef, breaks, grid, vlim, alim, sd_end, flags, mode), (d, N) = workloads(fam, B, seed)
-                res, rc = run(coef, breaks, grid, vlim, alim, sd_end, flags, mode)
+                res, rc = run(coef, breaks, grid, vlim, alim, sd_end, flags, mode, legacy=legacy)
                 res["family"] = fam
                 res["seed"] = seed
                 print(json.dumps(res), flush=True)

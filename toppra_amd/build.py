@@ -75,12 +75,40 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
         jobs.append((os.path.join(CSRC, "tpr_dense_tu.hip"), os.path.join(tmp, "dense.o"), []))  # dense rows: any constraint list
         jobs.sort(key=lambda j: 0 if ("robust" in j[1] or "main" in j[1] or "dense" in j[1]) else 1)  # the longest units first
 
+        # Object cache (build/objcache, git-ignored): an object is reused when its source, every file of csrc/ + the header
+        # and its flags are unchanged.  Development shortcut: TPR_BUILD_ONLY_CERT_DOFS="7 12" recompiles only those dofs of
+        # kernel family 3 and takes the other dofs' objects from the cache even when they are stale (never for a release
+        # build: __graft_entry__.build() does not set it).
+        import hashlib
+        cache = os.path.join(HERE, "..", "build", "objcache")
+        os.makedirs(cache, exist_ok=True)
+        dep_hash = hashlib.sha256()
+        for path in sorted(deps()):
+            with open(path, "rb") as fh:
+                dep_hash.update(fh.read())
+        only = os.environ.get("TPR_BUILD_ONLY_CERT_DOFS", "").split()
+
         def run(job):
             src, obj, extra = job
+            key = hashlib.sha256((dep_hash.hexdigest() + " ".join(cflags + dflags + extra) + os.path.basename(src)).encode()).hexdigest()[:24]
+            name = os.path.basename(obj)[:-2]
+            cached = os.path.join(cache, "%s_%s.o" % (name, key))
+            stale_ok = only and name.startswith("cert") and name[4:] not in only
+            if stale_ok and not os.path.exists(cached):
+                olds = sorted((f for f in os.listdir(cache) if f.startswith(name + "_")), key=lambda f: os.path.getmtime(os.path.join(cache, f)))
+                if olds:
+                    cached = os.path.join(cache, olds[-1])
+            if os.path.exists(cached):
+                shutil.copyfile(cached, obj)
+                return obj
             cmd = [cc] + cflags + dflags + extra + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd, cwd=CSRC)
+            for f in os.listdir(cache):  # one object per unit
+                if f.startswith(name + "_"):
+                    os.remove(os.path.join(cache, f))
+            shutil.copyfile(obj, cached)
             return obj
 
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:

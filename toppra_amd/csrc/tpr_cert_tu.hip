@@ -26,7 +26,14 @@
 // instantiation bit-exact, as are the neighbouring dofs, Collocation, and every fast instantiation (DESIGN.md section
 // 3.2).  Sound requests above 8 dof are served by the rows-across-lanes kernels, whose sound mode is bit-exact there.
 // -2 = not instantiated.
-constexpr bool kSoundHere = true;  // round 4: the trace-following sound certificates, every dof of this family
+// Round 4: the certificates follow the reference's whole pivot trace (tpr_cert_lane.hip.inc: cert_propose_sound & co) -- the
+// only mode of the product; TPR_SOUND_CERTIFICATES is accepted and changes nothing.  The round-2/3 "fast" certificates
+// (last pivot only) survive in the opt-in tolerance measurement build.
+#ifdef TPR_TOLERANCE_MODE
+constexpr bool kSoundKernels = false;
+#else
+constexpr bool kSoundKernels = true;
+#endif
 
 #define TPR_TU_CAT2(a, b) a##b
 #define TPR_TU_CAT(a, b) TPR_TU_CAT2(a, b)
@@ -51,11 +58,10 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_laun
     // (DESIGN.md section 4.1); above 8 dof the grid is read from global memory.
     const bool grid_lds = D <= 8 && !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
-    const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
     // One 64-lane block per wave; ~39 KB of LDS per block leaves one wave per SIMD, which the kernel
     // is written for (the whole register file, stalls covered by unrolled independent row work).
 #define TPR_LAUNCH_CERT(SD, GL, IN, SO) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, SD, GL, IN, SO>), grid, block, lds, stream, G)
-#define TPR_LAUNCH_CERT3(SD, GL, IN) do { if (sound) { if constexpr (kSoundHere) TPR_LAUNCH_CERT(SD, GL, IN, true); else return -2; } else TPR_LAUNCH_CERT(SD, GL, IN, false); } while (0)
+#define TPR_LAUNCH_CERT3(SD, GL, IN) TPR_LAUNCH_CERT(SD, GL, IN, kSoundKernels)
     if (G.flags & TPR_ACC_INTERPOLATION) {
         if (G.sd) { if (grid_lds) TPR_LAUNCH_CERT3(true, true, true); else TPR_LAUNCH_CERT3(true, false, true); }
         else { if (grid_lds) TPR_LAUNCH_CERT3(false, true, true); else TPR_LAUNCH_CERT3(false, false, true); }
@@ -85,10 +91,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feas
     // (DESIGN.md section 4.1); above 8 dof the grid is read from global memory.
     const bool grid_lds = D <= 8 && !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
-    const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
     const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;
 #define TPR_LAUNCH_FEAS(GL, IN, SO) hipLaunchKernelGGL((tpr::cert_feasible_kernel<D, BS, GL, IN, SO>), grid, block, lds, stream, G, X)
-#define TPR_LAUNCH_FEAS2(GL, IN) do { if (sound) { if constexpr (kSoundHere) TPR_LAUNCH_FEAS(GL, IN, true); else return -2; } else TPR_LAUNCH_FEAS(GL, IN, false); } while (0)
+#define TPR_LAUNCH_FEAS2(GL, IN) TPR_LAUNCH_FEAS(GL, IN, kSoundKernels)
     if (interp) { if (grid_lds) TPR_LAUNCH_FEAS2(true, true); else TPR_LAUNCH_FEAS2(false, true); }
     else { if (grid_lds) TPR_LAUNCH_FEAS2(true, false); else TPR_LAUNCH_FEAS2(false, false); }
 #undef TPR_LAUNCH_FEAS2
@@ -113,10 +118,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_l
     // (DESIGN.md section 4.1); above 8 dof the grid is read from global memory.
     const bool grid_lds = D <= 8 && !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
-    const bool sound = (G.flags & TPR_SOUND_CERTIFICATES) != 0;
     const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;
 #define TPR_LAUNCH_SD(GL, IN, SO) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, false, GL, IN, SO, true>), grid, block, lds, stream, G)
-#define TPR_LAUNCH_SD2(GL, IN) do { if (sound) { if constexpr (kSoundHere) TPR_LAUNCH_SD(GL, IN, true); else return -2; } else TPR_LAUNCH_SD(GL, IN, false); } while (0)
+#define TPR_LAUNCH_SD2(GL, IN) TPR_LAUNCH_SD(GL, IN, kSoundKernels)
     if (interp) { if (grid_lds) TPR_LAUNCH_SD2(true, true); else TPR_LAUNCH_SD2(false, true); }
     else { if (grid_lds) TPR_LAUNCH_SD2(true, false); else TPR_LAUNCH_SD2(false, false); }
 #undef TPR_LAUNCH_SD2
