@@ -12,7 +12,6 @@
 #include "tpr_device.hpp"
 #include "tpr_group.hip.inc"
 #include "tpr_cert.hip.inc"
-#include "tpr_cert2w.hip.inc"
 
 #ifndef TPR_TU_D
 #error "compile with -DTPR_TU_D=<dof 1..8>"
@@ -129,28 +128,3 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_l
     return 0;
 }
 
-// The two-wave form of the certified lane kernel (tpr_cert2w.hip.inc): up to 8 dof, the fused solve or the backward scan alone.
-#if TPR_TU_D <= 8 && !defined(TPR_TOLERANCE_MODE)
-extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert2w_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, hipStream_t stream) {
-    constexpr int D = TPR_TU_D, BS = 64;
-    const tpr::GroupArgs &G = *Gp;
-    const dim3 grid((G.B + BS - 1) / BS), block(2 * BS);
-    const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
-    using CS = tpr::CertStage<D, BS>;
-    const size_t static_lds = (((4 * D + CS::kLimCols) > 24 ? (4 * D + CS::kLimCols) : 24) * BS + tpr::kCertXch * BS +
-                               tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + 2 * 2 * BS + 3 * BS) * sizeof(double);
-    // the shared grid goes to LDS only while four blocks (eight waves: two per SIMD) still fit a CU
-    const bool grid_lds = !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
-    const size_t lds = grid_lds ? grid_bytes : 0;
-#define TPR_LAUNCH_2W(SD, GL, IN) hipLaunchKernelGGL((tpr::cert2w_solve_kernel<D, BS, SD, GL, IN>), grid, block, lds, stream, G)
-    if (G.flags & TPR_ACC_INTERPOLATION) {
-        if (G.sd) { if (grid_lds) TPR_LAUNCH_2W(true, true, true); else TPR_LAUNCH_2W(true, false, true); }
-        else { if (grid_lds) TPR_LAUNCH_2W(false, true, true); else TPR_LAUNCH_2W(false, false, true); }
-    } else {
-        if (G.sd) { if (grid_lds) TPR_LAUNCH_2W(true, true, false); else TPR_LAUNCH_2W(true, false, false); }
-        else { if (grid_lds) TPR_LAUNCH_2W(false, true, false); else TPR_LAUNCH_2W(false, false, false); }
-    }
-#undef TPR_LAUNCH_2W
-    return 0;
-}
-#endif

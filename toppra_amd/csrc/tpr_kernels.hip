@@ -44,14 +44,6 @@ __attribute__((visibility("hidden"))) int tpr_tu_dense_launch(const tpr::DenseAr
 __attribute__((visibility("hidden"))) int tpr_tu_robust_launch_lo(const tpr::RobustArgs *, size_t, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_robust_launch_hi(const tpr::RobustArgs *, size_t, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_robust_lane_launch(const tpr::RobustArgs *, hipStream_t);
-__attribute__((visibility("hidden"))) int tpr_tu_cert2w_launch_1(const tpr::GroupArgs *, hipStream_t);
-__attribute__((visibility("hidden"))) int tpr_tu_cert2w_launch_2(const tpr::GroupArgs *, hipStream_t);
-__attribute__((visibility("hidden"))) int tpr_tu_cert2w_launch_3(const tpr::GroupArgs *, hipStream_t);
-__attribute__((visibility("hidden"))) int tpr_tu_cert2w_launch_4(const tpr::GroupArgs *, hipStream_t);
-__attribute__((visibility("hidden"))) int tpr_tu_cert2w_launch_5(const tpr::GroupArgs *, hipStream_t);
-__attribute__((visibility("hidden"))) int tpr_tu_cert2w_launch_6(const tpr::GroupArgs *, hipStream_t);
-__attribute__((visibility("hidden"))) int tpr_tu_cert2w_launch_7(const tpr::GroupArgs *, hipStream_t);
-__attribute__((visibility("hidden"))) int tpr_tu_cert2w_launch_8(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_launch_1(const tpr::GroupArgs *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_feasible_launch_1(const tpr::GroupArgs *, double *, hipStream_t);
 __attribute__((visibility("hidden"))) int tpr_tu_cert_sd_launch_1(const tpr::GroupArgs *, hipStream_t);
@@ -390,29 +382,6 @@ int launch_cert(const tpr::BatchArgs &A, hipStream_t stream) {
     return fail(TPR_E_UNSUPPORTED, "variant 3: dof not instantiated");
 }
 
-// The two-wave form of family 3 (tpr_cert2w.hip.inc; variant 5): up to 8 dof.
-bool cert2w_supported(const tpr::BatchArgs &A) { return cert_supported(A) && A.d <= 8; }
-int launch_cert2w(const tpr::BatchArgs &A, hipStream_t stream) {
-    tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
-                     A.sd_start, A.sd_end, A.sd2, A.sd, A.u, A.K, A.status, A.sd_end_hi, A.backward_only};
-#ifndef TPR_TOLERANCE_MODE  // (the tolerance measurement build does not carry it)
-    switch (A.d) {
-#ifndef TPR_CERT_DEV
-        case 1: return cert_tu_rc(tpr_tu_cert2w_launch_1(&G, stream));
-        case 2: return cert_tu_rc(tpr_tu_cert2w_launch_2(&G, stream));
-        case 3: return cert_tu_rc(tpr_tu_cert2w_launch_3(&G, stream));
-        case 4: return cert_tu_rc(tpr_tu_cert2w_launch_4(&G, stream));
-        case 5: return cert_tu_rc(tpr_tu_cert2w_launch_5(&G, stream));
-        case 6: return cert_tu_rc(tpr_tu_cert2w_launch_6(&G, stream));
-        case 8: return cert_tu_rc(tpr_tu_cert2w_launch_8(&G, stream));
-#endif
-        case 7: return cert_tu_rc(tpr_tu_cert2w_launch_7(&G, stream));
-    }
-#endif
-    (void)G;
-    return fail(TPR_E_UNSUPPORTED, "variant 5: dof not instantiated");
-}
-
 // compute_feasible_sets on the certified lane design: the constraint sets and dofs of family 3, fresh warm-start state
 bool cert_feasible_supported(const tpr::BatchArgs &A) {
     return group_supported(A) && (A.flags & TPR_HAS_ACCELERATION) && A.d <= TPR_CERT_MAX_DOF &&
@@ -604,17 +573,12 @@ int pick_variant(int requested, const tpr::BatchArgs &A) {
 int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stream) {
     if (A.B == 0) return TPR_E_OK;
     const int variant = pick_variant(p->variant, A);
-    if (A.active && (variant == 2 || variant == 3 || variant == 5))
+    if (A.active && (variant == 2 || variant == 3))
         return fail(TPR_E_UNSUPPORTED, "tpr_problem.active (warm-start state in / out) is maintained by kernel families 4 and 1 only: leave variant at 0");
     switch (variant) {
         case 4: {
             if (!wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables (N <= 1480)");
             return launch_wave(A, stream);
-        }
-        case 5: {
-            if (!cert2w_supported(A))
-                return fail(TPR_E_UNSUPPORTED, "variant 5 (family 3 on two waves per block) needs an acceleration constraint, d <= 8, sd2/u/status outputs, no strict mode, no warm-start state");
-            return launch_cert2w(A, stream);
         }
         case 3: {
             if (!cert_supported(A))
