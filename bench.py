@@ -311,8 +311,8 @@ def baseline_configs(torch, tb, dev):
                 "problems solved exactly; parity unpinned against ECOS (absent), cross-checked at 1e-7 against an independent exact solver (tests/test_gpu_robust.py)"}
     res["C5_batch524288_8gpu"] = "this bench with --gpus 8 (65536 trajectories per rank + RCCL gather of sd^2)"
     res["large_batch262144_d7_N200"] = dict(kernel(262144, 7, 200, reps=3),
-                                            note="four rounds of one wave per SIMD: the kernel has no two-waves-per-SIMD variant (DESIGN.md 3.8)")
-    res["d12_batch65536_N200"] = dict(kernel(65536, 12, 200, reps=3), note="kernel family 3 at 12 dof: slim blocks, four per CU (DESIGN.md 3.2)")
+                                            note="four rounds of one wave per SIMD (a two-waves-per-block form was built and measured in round 4: slower, DESIGN.md 4.1)")
+    res["d12_batch65536_N200"] = dict(kernel(65536, 12, 200, reps=3), note="12 dof: the rows-across-lanes kernels (family 2, 16 lanes per trajectory); family 3 stops at 8 dof since round 4 (DESIGN.md 3.2)")
     # dense rows (any canonical-linear constraint list): the headline problem's own rows materialised as
     # seidelWrapper would hold them (144 KB per trajectory) and solved from those arrays -- the HBM-heavy form of the path
     datad = tb.make_synthetic_batch(65536, 7, 200)

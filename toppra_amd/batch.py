@@ -99,7 +99,7 @@ def solve_desired_duration_batch(coef, breaks, grid, vlim, alim, desired_duratio
 
     ``desired_duration``: scalar or [B] seconds.  Returns dict(sd2, sd, u, K, status, alpha): alpha is
     the blend between the fastest (1) and slowest (0) parameterizations found by bisection.
-    ``variant``: 0 = auto (from 14336 trajectories up to 8 dof, 20480 at 9..13 dof: the certified lane kernel runs the backward scan and both
+    ``variant``: 0 = auto (from 14336 trajectories up to 8 dof: the certified lane kernel runs the backward scan and both
     forward profiles in one launch; rows across lanes otherwise), 2 / 3 force one.  ``squared``: sd_start / sd_end already
     hold sd^2 (TPR_BOUNDARY_SQUARED)."""
     _prepare(coef)
@@ -257,7 +257,7 @@ def feasible_sets_batch(coef, breaks, grid, vlim, alim, interpolation=True, acti
     """compute_feasible_sets for B trajectories -> X[B,N+1,2] (``active``: see solve_batch).
 
     ``variant``: 0 = auto (one trajectory per wave for a handful of trajectories or with ``active``; the certified lane
-    kernel from 8192 trajectories up to 8 dof, from 20480 at 9..13 dof; rows across lanes otherwise), 2 / 3 / 4 force a kernel family.
+    kernel from 8192 trajectories up to 8 dof; rows across lanes otherwise), 2 / 3 / 4 force a kernel family.
     ``strict`` (TPR_STRICT_SEIDEL): the reference's full iteration for every LP; ``sound``: see solve_batch."""
     _prepare(coef)
     p, keep = _capi.make_problem(coef, breaks, grid, vlim, alim, None, None, interpolation, active=active, variant=variant,

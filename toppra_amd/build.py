@@ -40,11 +40,11 @@ def stale():
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in deps())
 
 
-# kernel family 3: one translation unit per dof (csrc/tpr_cert_tu.hip), 1..13: above that a block no longer fits a quarter of a
-# CU's LDS (four blocks per CU = one wave per SIMD = a 65536-trajectory batch in one round) and the rows-across-lanes kernels
-# are faster (65536 x 14 x 200: 9.3 vs 8.6 ms).
-# TPR_BUILD_CERT_MAX_DOF=8 for quicker development builds
-CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "13"))
+# kernel family 3: one translation unit per dof (csrc/tpr_cert_tu.hip), 1..8.  Round 3 shipped slim blocks for 9..13 dof
+# (3.6 ms at 65536 x 12 x 200 with the last-pivot-only certificates); with the trace-following certificates of round 4
+# those instantiations no longer fit the register file (2.5 KB of scratch per lane at 12 dof: 19 ms) and the rows-across-lanes
+# kernels are faster there (9.5 ms), so 9..16 dof are theirs.  TPR_BUILD_CERT_MAX_DOF=13 still builds them (experiments).
+CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "8"))
 CERT_DOFS = tuple(range(1, CERT_MAX_DOF + 1))
 
 

@@ -23,7 +23,7 @@
 
 #define TPR_TU_CAT3_(a, b) a##b
 #define TPR_TU_CAT3(a, b) TPR_TU_CAT3_(a, b)
-// kernel family 3, one translation unit per dof (tpr_cert_tu.hip): 1..TPR_CERT_MAX_DOF (build.py: 13)
+// kernel family 3, one translation unit per dof (tpr_cert_tu.hip): 1..TPR_CERT_MAX_DOF (build.py: 8)
 #ifndef TPR_CERT_MAX_DOF
 #define TPR_CERT_MAX_DOF 8
 #endif
@@ -564,9 +564,7 @@ int pick_variant(int requested, const tpr::BatchArgs &A) {
     // fixed-latency round, which beats family 2's throughput from about a quarter of that batch upward
     // (tools/gpu_crossover.py); family 2 serves the strict mode and what is left.
     if (wave_supported(A) && A.B <= TPR_WAVE_AUTO_MAX_BATCH) return 4;
-    // (9..13 dof: slim blocks, one round of 2.2 .. 3.6 ms up to 65536 trajectories against family 2's 7.7 .. 8.6 ms per
-    // 65536: tools/gpu_cert_dofs_check.py)
-    if (cert_supported(A) && A.B >= (A.d <= 8 ? 14336 : 20480)) return 3;
+    if (cert_supported(A) && A.B >= 14336) return 3;
     return group_supported(A) ? 2 : (wave_supported(A) ? 4 : 1);
 }
 
@@ -582,7 +580,7 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
         }
         case 3: {
             if (!cert_supported(A))
-                return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 13 (8 with sound certificates), sd2/u/status outputs, no strict mode");
+                return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 8, sd2/u/status outputs, no strict mode");
             return launch_cert(A, stream);
         }
         case 2: {
@@ -839,10 +837,10 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
         tpr::BatchArgs Ab = A;
         Ab.backward_only = 1;
         // p->variant: 0 = auto; 2 / 3 force the rows-across-lanes scans / the certified lane kernel for both scans
-        const bool fused = p->variant == 3 || (p->variant == 0 && cert_supported(Ab) && A.B >= (A.d <= 8 ? 14336 : 20480));
+        const bool fused = p->variant == 3 || (p->variant == 0 && cert_supported(Ab) && A.B >= 14336);
         if (fused) {
             // family 3: backward scan + fastest / slowest forward profiles in ONE launch (cert_solve_kernel<SDFWD>)
-            if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 13 (8 with sound certificates), no strict mode");
+            if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 8, no strict mode");
             if (int rc = launch_cert_sd(A, xf, uf, xl, ul, stream)) return rc;
         } else {
             // backward scan -> K and the controllability verdict (the time-optimal forward scan is not needed), then
@@ -1213,7 +1211,7 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
         const int want = p->variant;
         const bool wave_auto = wave_supported(A) && (A.active || A.B <= 64 || !group_supported(A));
         if (want == 3 && !cert_feasible_supported(A))
-            return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 13 (8 with sound certificates), no strict mode, no warm-start state");
+            return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 8, no strict mode, no warm-start state");
         if (want == 4 && !wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables");
         if (A.active && (want == 2 || want == 3))
             return fail(TPR_E_UNSUPPORTED, "tpr_problem.active (warm-start state in / out) is maintained by kernel families 4 and 1 only: leave variant at 0");
@@ -1224,7 +1222,7 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
             // warm-start state in / out
             A.feasible_X = dX;
             if (int rc = launch_wave(A, stream)) return rc;
-        } else if (want == 3 || (want == 0 && cert_feasible_supported(A) && A.B >= (A.d <= 8 ? 8192 : 20480))) {
+        } else if (want == 3 || (want == 0 && cert_feasible_supported(A) && A.B >= 8192)) {
             // one trajectory per lane, certified answers (family 3): a fixed-latency round up to 65536 trajectories
             if (int rc = launch_cert_feasible(A, dX, stream)) return rc;
         } else if (group_supported(A) && want != 1) {
