@@ -19,11 +19,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from toppra_amd import batch  # noqa: E402  (host-side generator only)
 
-EXE = os.path.join(tempfile.gettempdir(), "tpr_host_cert")
+EXE = os.environ.get("TPR_HOST_CERT_EXE") or os.path.join(tempfile.gettempdir(), "tpr_host_cert")
 FLAG_VEL, FLAG_ACC, FLAG_INTERP = 1, 2, 4
 
 
 def build(force=False):
+    if os.environ.get("TPR_HOST_CERT_EXE"):   # a frozen copy (long hunts running beside a rebuild)
+        return EXE
     srcs = [os.path.join(ROOT, "tests", "host_cert", "host_cert.cpp"), os.path.join(ROOT, "oracle", "seidel_oracle.c"),
             os.path.join(ROOT, "toppra_amd", "csrc", "tpr_cert_lane.hip.inc"), os.path.join(ROOT, "toppra_amd", "csrc", "tpr_device.hpp")]
     if not force and os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(s) for s in srcs):
