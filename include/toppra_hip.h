@@ -83,7 +83,7 @@ typedef struct tpr_problem {
     int32_t B, d, nseg, N;
     int32_t flags;
     int32_t variant; /* kernel selection: 0 = auto, 1 = generic lane-per-trajectory, 2 = rows-across-lanes,
-                        3 = lane-per-trajectory certificates (d <= 8; sd2, u, status required),
+                        3 = lane-per-trajectory certificates (d <= 13; sd2, u, status required),
                         4 = one trajectory per wave (the latency kernel: any dof, N <= 1480; auto for
                             small batches) */
     const double *coef;

@@ -57,6 +57,7 @@ struct Runner {
     // one lane's "LDS columns" (BS = 1): q', q'' of the two gridpoints (two parities) and the row constants
     double q[2][2][D];
     double lim[6 + 2 * D];
+    double alim_lane[2 * D];
     C S;
 
     void report(const char *what, int b, int i, const tpr::Lp2dOut &o, const double *ref, long r0, long r1) {
@@ -78,6 +79,8 @@ struct Runner {
             S.cneg[k] = WC[2 + D + k];      // +amin
         }
         S.lim = lim;
+        for (int k = 0; k < D; ++k) { alim_lane[2 * k] = S.cneg[k]; alim_lane[2 * k + 1] = -S.cpos[k]; }
+        S.alim_lane = alim_lane;
         lim[0] = tpr::kVarMin; lim[1] = -tpr::kVarMax;
         S.cmax = 0.0; S.min_range = 3.0e300;
         for (int k = 0; k < D; ++k) {

@@ -76,7 +76,7 @@ def test_lower_bound_shortcut_is_exact(gpu, B, d, N, seed):
         args = (coef, data["breaks"], data["grid"], data["vlim"], data["alim"], s0, s1)
         full = batch.solve_batch(*args, strict=True)
         assert len(np.unique(full["status"])) >= (1 if s0 is not None else 2)
-        # rows-across-lanes with shortcuts; certified lane kernel (default for large batches, d <= 8); one trajectory
+        # rows-across-lanes with shortcuts; certified lane kernel (default for large batches, d <= 13); one trajectory
         # per wave (default for small batches)
         for variant in (2, 3, 4):
             fast = batch.solve_batch(*args, variant=variant)
@@ -323,7 +323,7 @@ def test_concurrent_rows_and_sliver_pivots_are_bit_exact(gpu, B, d, N, seed):
     full = batch.solve_batch(*args, strict=True)
     assert 0.02 < (full["status"] == 0).mean() < 0.999  # the family is hard: many of them fail in the reference too
     for variant in (4, 2, 3):
-        if variant == 3 and d > 8:
+        if variant == 3 and d > 13:
             continue
         got = batch.solve_batch(*args, variant=variant)
         bad = got["status"] != full["status"]

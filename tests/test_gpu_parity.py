@@ -142,7 +142,7 @@ def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
     args = (data["coef"], data["breaks"], data["grid"], vlim, alim, None, sd1, interp)
     lane = batch.solve_batch(*args, variant=1)
     kws = [dict(variant=2), dict(variant=2, strict=True), dict(), dict(variant=4), dict(variant=4, strict=True)]
-    if alim is not None and d <= 8:
+    if alim is not None and d <= 13:
         kws.append(dict(variant=3))  # the certified lane kernel: Interpolation and Collocation, velocity optional
     for kw in kws:
         got = batch.solve_batch(*args, **kw)
@@ -157,13 +157,12 @@ def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
     assert X.shape == (64, N + 1, 2) and not np.isnan(X).any()
 
 
-@pytest.mark.parametrize("d", [9, 12, 13])
-def test_above_8_dof_is_served_by_the_rows_across_lanes_kernels(gpu, d):
-    """Round 4: family 3 (one trajectory per lane) stops at 8 dof -- its trace-following certificates no longer fit the
-    register file above (2.5 KB of scratch per lane at 12 dof) -- and 9..16 dof run the rows-across-lanes kernels
-    automatically, at any batch size: solve, feasible sets and TOPPRAsd against the full iteration / the explicit variant,
-    bit for bit; asking for variant 3 there is refused."""
-    from toppra_amd import _capi
+@pytest.mark.parametrize("d", [9, 10, 11, 12, 13])
+def test_certified_lane_kernel_above_8_dof(gpu, d):
+    """Family 3 serves 9..13 dof too (slim blocks, internal row numbering with a block stride of 16, three mask words for the
+    80 row numbers), with the same trace-following certificates as below -- there is no other mode: solve (scaled paths,
+    boundary velocities, Collocation), feasible sets and TOPPRAsd against the rows-across-lanes kernels -- the full iteration
+    where there is a strict mode -- bit for bit, explicitly and through the default choice."""
     B, N = 1200, 50
     data = batch.make_synthetic_batch(B, d, N, seed=60 + d)
     rng = np.random.default_rng(d)
@@ -173,15 +172,35 @@ def test_above_8_dof_is_served_by_the_rows_across_lanes_kernels(gpu, d):
     for interp in (True, False):
         args = (data["coef"] * scale, data["breaks"], data["grid"], data["vlim"], data["alim"], sd0, sd1, interp)
         full = batch.solve_batch(*args, variant=2, strict=True)
-        got = batch.solve_batch(*args)
-        for k in ("K", "sd2", "u", "status"):
-            assert np.array_equal(got[k], full[k], equal_nan=True), (k, interp)
-        with pytest.raises(_capi.ToppraHipError):
-            batch.solve_batch(*args, variant=3)
+        for kw in (dict(variant=3), dict(variant=3, sound=True), dict()):
+            got = batch.solve_batch(*args, **kw)
+            for k in ("K", "sd2", "u", "status"):
+                assert np.array_equal(got[k], full[k], equal_nan=True), (k, interp, kw)
         fargs = args[:5] + (interp,)
-        assert np.array_equal(batch.feasible_sets_batch(*fargs), batch.feasible_sets_batch(*fargs, variant=2, strict=True), equal_nan=True)
+        assert np.array_equal(batch.feasible_sets_batch(*fargs, variant=3), batch.feasible_sets_batch(*fargs, variant=2, strict=True), equal_nan=True)
         desired = rng.uniform(0.3, 6.0, size=B)
         want = batch.solve_desired_duration_batch(*args[:5], desired, sd0, sd1, variant=2, interpolation=interp)
-        got = batch.solve_desired_duration_batch(*args[:5], desired, sd0, sd1, interpolation=interp)
+        got = batch.solve_desired_duration_batch(*args[:5], desired, sd0, sd1, variant=3, interpolation=interp)
         for k in ("K", "sd2", "u", "status", "alpha"):
             assert np.array_equal(got[k], want[k], equal_nan=True), (k, interp)
+
+
+@pytest.mark.parametrize("B,d,N", [(1, 9, 7), (65, 13, 5), (3, 12, 2), (130, 10, 1)])
+def test_slim_blocks_partial_and_tiny(gpu, B, d, N):
+    """The slim blocks of family 3 above 8 dof read the acceleration limits (their own in a row fetch, another lane's in the
+    cooperative batches) from global memory and flush K two stages at a time: partial blocks (idle lanes shadow the last
+    trajectory), odd and tiny stage counts."""
+    data = batch.make_synthetic_batch(B, d, N, seed=7 * d + N)
+    rng = np.random.default_rng(B)
+    sd1 = np.where(rng.random(B) < 0.5, 0.2 * rng.random(B), 0.0)
+    scale = 10.0 ** rng.uniform(-4, 0, size=(B, 1, 1, 1))
+    for interp in (True, False):
+        args = (data["coef"] * scale, data["breaks"], data["grid"], data["vlim"], data["alim"], None, sd1, interp)
+        full = batch.solve_batch(*args, variant=2, strict=True)
+        got = batch.solve_batch(*args, variant=3)
+        for k in ("K", "sd2", "u", "status"):
+            assert np.array_equal(got[k], full[k], equal_nan=True), (k, interp)
+        fargs = args[:5] + (interp,)
+        assert np.array_equal(batch.feasible_sets_batch(*fargs, variant=3), batch.feasible_sets_batch(*fargs, variant=2, strict=True), equal_nan=True)
+        K = batch.controllable_sets_batch(*args[:5], 0.0, sd1, interp, variant=3)
+        assert np.array_equal(K, batch.controllable_sets_batch(*args[:5], 0.0, sd1, interp, variant=2, strict=True), equal_nan=True)

@@ -40,11 +40,12 @@ def stale():
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in deps())
 
 
-# kernel family 3: one translation unit per dof (csrc/tpr_cert_tu.hip), 1..8.  Round 3 shipped slim blocks for 9..13 dof
-# (3.6 ms at 65536 x 12 x 200 with the last-pivot-only certificates); with the trace-following certificates of round 4
-# those instantiations no longer fit the register file (2.5 KB of scratch per lane at 12 dof: 19 ms) and the rows-across-lanes
-# kernels are faster there (9.5 ms), so 9..16 dof are theirs.  TPR_BUILD_CERT_MAX_DOF=13 still builds them (experiments).
-CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "8"))
+# kernel family 3: one translation unit per dof (csrc/tpr_cert_tu.hip), 1..13 (slim blocks above 8 dof).  Round 4's
+# trace-following certificates first pushed the 9..13-dof instantiations far out of the register file (1.4 - 2.4 KB of scratch
+# per lane: 10.6 - 22 ms at 65536 x d x 200); the cause was one conditionally-needed load in CertStage::fetch that the compiler
+# sank into divergent regions (tpr_cert_lane.hip.inc), and without it they are back at 0 - 0.7 KB: 3.0 / 4.6 / 7.8 / 7.7 /
+# 10.9 ms at 9..13 dof against 10.2 - 12.0 for the rows-across-lanes kernels.
+CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "13"))
 CERT_DOFS = tuple(range(1, CERT_MAX_DOF + 1))
 
 
