@@ -242,9 +242,11 @@ def tolerance_probe(B, d, N, seed, sd2, status):
             "max_abs_dsd2_vs_product": float(np.nanmax(np.abs(tol_sd2 - sd2))),
             "status_identical": bool(np.array_equal(tol_status, status)),
             "nan_pattern_identical": bool(np.array_equal(np.isnan(tol_sd2), np.isnan(sd2))),
-            "note": "NOT the product: measurement build answering 'what does bit-exactness cost' (the product replicates the "
-                    "reference's last-pivot arithmetic FMA-free with correctly rounded divisions; this build returns the "
-                    "certified vertex itself, with contracted multiply-adds and reciprocal division).  The north star's bar is "
+            "note": "NOT the product: measurement build answering 'what do the reference's bits cost' (the product predicts the "
+                    "reference's whole pivot trace before it answers an LP from a certificate and replicates its last-pivot "
+                    "arithmetic FMA-free with correctly rounded divisions; this build certifies the final vertex only -- round 3's "
+                    "certificates, which return an optimum where a sliver pivot ends the reference's run -- and returns that vertex "
+                    "itself, with contracted multiply-adds and reciprocal division).  The north star's bar is "
                     "1e-8 on sd^2; tools/gpu_tolerance_report.py checks every fixture (profiles/r04_tolerance_report.json)"}
 
 
@@ -312,7 +314,7 @@ def baseline_configs(torch, tb, dev):
     res["C5_batch524288_8gpu"] = "this bench with --gpus 8 (65536 trajectories per rank + RCCL gather of sd^2)"
     res["large_batch262144_d7_N200"] = dict(kernel(262144, 7, 200, reps=3),
                                             note="four rounds of one wave per SIMD (a two-waves-per-block form was built and measured in round 4: slower, DESIGN.md 4.1)")
-    res["d12_batch65536_N200"] = dict(kernel(65536, 12, 200, reps=3), note="12 dof: the rows-across-lanes kernels (family 2, 16 lanes per trajectory); family 3 stops at 8 dof since round 4 (DESIGN.md 3.2)")
+    res["d12_batch65536_N200"] = dict(kernel(65536, 12, 200, reps=3), note="12 dof: family 3 with slim blocks and the trace-following certificates (DESIGN.md 3.2); rows across lanes: 12.1 ms")
     # dense rows (any canonical-linear constraint list): the headline problem's own rows materialised as
     # seidelWrapper would hold them (144 KB per trajectory) and solved from those arrays -- the HBM-heavy form of the path
     datad = tb.make_synthetic_batch(65536, 7, 200)

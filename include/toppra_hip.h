@@ -145,7 +145,7 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream);
  * "slowest" forward scans, the duration bisection on their convex combination (absolute tolerance
  * atol, reference default 1e-5) and the blended sd^2 / u.  desired [B] seconds; alpha [B] (may be
  * NULL) receives the blend factor.  Same result struct and status codes as tpr_solve_batch; up to 16 dof.
- * p->variant: 0 = auto -- from 14336 trajectories up to 8 dof the certified lane kernel runs the
+ * p->variant: 0 = auto -- from 9216 trajectories (9..10 dof: 18432, 11..13 dof: 22528) the certified lane kernel runs the
  * backward scan and both forward profiles in ONE launch, the rows-across-lanes kernels otherwise; 2 / 3 force one.
  * Bisection and blend: one wave per trajectory.                                                      */
 int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired, double atol,

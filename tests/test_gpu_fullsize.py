@@ -87,7 +87,7 @@ def test_lower_bound_shortcut_is_exact(gpu, B, d, N, seed):
 @pytest.mark.parametrize("B,d,N,seed", [(65536, 7, 200, 21), (20480, 4, 120, 22), (16384, 8, 64, 23)])
 def test_collocation_on_the_certified_lane_kernel(gpu, B, d, N, seed):
     """Collocation at full size: the certified lane kernel (the interpolation blocks are null rows there; default
-    from 14 336 trajectories) against the full Seidel iteration of family 2 (disabled rows), bit for bit, with
+    from 9 216 trajectories) against the full Seidel iteration of family 2 (disabled rows), bit for bit, with
     and without the velocity constraint, incl. non-zero boundary velocities and badly scaled paths."""
     data = batch.make_synthetic_batch(B, d, N, seed=seed)
     rng = np.random.default_rng(seed)

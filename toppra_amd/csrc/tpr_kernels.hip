@@ -553,6 +553,9 @@ int launch_wave(const tpr::BatchArgs &A, hipStream_t stream) {
     return TPR_E_OK;
 }
 
+// Batch size from which family 3 is the automatic choice (solve, TOPPRAsd).
+int cert_auto_from(int d) { return d <= 8 ? 9216 : (d <= 10 ? 18432 : 22528); }
+
 // Kernel family of a solve (tpr_problem.variant 0 = auto).
 int pick_variant(int requested, const tpr::BatchArgs &A) {
     if (requested != 0) return requested;
@@ -564,7 +567,10 @@ int pick_variant(int requested, const tpr::BatchArgs &A) {
     // fixed-latency round, which beats family 2's throughput from about a quarter of that batch upward
     // (tools/gpu_crossover.py); family 2 serves the strict mode and what is left.
     if (wave_supported(A) && A.B <= TPR_WAVE_AUTO_MAX_BATCH) return 4;
-    if (cert_supported(A) && A.B >= 14336) return 3;
+    // (round 4, after families 2 and 4 learnt to follow the lower-bound trace too: at 7 dof family 2 leads between ~5600 and
+    // ~9200 trajectories, 1.7 - 1.9 ms against family 3's 2.1 - 2.2 at any size up to 65536; the slim blocks of 9..13 dof
+    // take 3.2 - 4.4 ms for a partial round and pay from ~18000 / ~22000 trajectories: profiles/r04_family_crossover.log)
+    if (cert_supported(A) && A.B >= cert_auto_from(A.d)) return 3;
     return group_supported(A) ? 2 : (wave_supported(A) ? 4 : 1);
 }
 
@@ -837,7 +843,7 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
         tpr::BatchArgs Ab = A;
         Ab.backward_only = 1;
         // p->variant: 0 = auto; 2 / 3 force the rows-across-lanes scans / the certified lane kernel for both scans
-        const bool fused = p->variant == 3 || (p->variant == 0 && cert_supported(Ab) && A.B >= 14336);
+        const bool fused = p->variant == 3 || (p->variant == 0 && cert_supported(Ab) && A.B >= cert_auto_from(A.d));
         if (fused) {
             // family 3: backward scan + fastest / slowest forward profiles in ONE launch (cert_solve_kernel<SDFWD>)
             if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 13, no strict mode");
