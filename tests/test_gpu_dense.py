@@ -296,3 +296,26 @@ def test_dense_rows_at_the_headline_shape(gpu):
     for k in ("K", "sd2", "u", "status"):
         assert torch.equal(torch.nan_to_num(got[k].double(), nan=-7.0), torch.nan_to_num(ref[k].double(), nan=-7.0)), k
     assert float((ref["status"] == 0).double().mean()) > 0.99
+
+
+@pytest.mark.parametrize("B,d,N,interp,vel,acc", [(4096, 7, 200, True, True, True), (513, 7, 33, False, True, True), (64, 12, 50, True, True, True),
+                                                  (40, 32, 9, True, True, True), (100, 3, 1, True, False, True), (77, 5, 20, True, True, False)])
+def test_constraint_params_rows_are_the_wrappers(gpu, oracle, B, d, N, interp, vel, acc):
+    """tpr_constraint_params_batch (one thread per element of a, b, c since round 4) against the restatement of
+    seidelWrapper.__init__ (cy_seidel_solverwrapper.pyx:440-470): every element of a, b, c, low, high -- incl. the last
+    gridpoint's repeated interpolation block, Collocation, no velocity / no acceleration constraint, non-uniform grids and
+    knots, 32 dof, a single stage."""
+    rng = np.random.default_rng(B + N)
+    data = batch.make_synthetic_batch(B, d, N, seed=7 + d)
+    grid = np.concatenate([[0.0], np.sort(rng.random(N - 1)) * 0.98 + 0.01, [1.0]]) if N > 1 else data["grid"]
+    vlim = data["vlim"] if vel else None
+    alim = data["alim"] if acc else None
+    rows = batch.constraint_params_batch(data["coef"], data["breaks"], grid, vlim, alim, interp)
+    flags = (1 if vel else 0) | (2 if acc else 0) | (4 if interp else 0)
+    for bsel in sorted(set([0, B - 1] + list(rng.integers(0, B, 6)))):
+        w = oracle.Wrapper(data["coef"][bsel], data["breaks"], grid, None if vlim is None else vlim[bsel], None if alim is None else alim[bsel], flags=flags)
+        assert rows["a"].shape[2] == w.nC
+        wa, wb, wc = w.a_arr, w.b_arr, w.c_arr
+        wa[:, :2] = 0; wb[:, :2] = 0; wc[:, :2] = 0   # rows 0, 1 (the x_next pair) are per-solve values: zeros in the entry's output
+        assert_same(rows["a"][bsel], wa, "a"); assert_same(rows["b"][bsel], wb, "b"); assert_same(rows["c"][bsel], wc, "c")
+        assert_same(rows["low"][bsel], w.low_arr, "low"); assert_same(rows["high"][bsel], w.high_arr, "high")

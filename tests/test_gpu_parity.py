@@ -204,3 +204,28 @@ def test_slim_blocks_partial_and_tiny(gpu, B, d, N):
         assert np.array_equal(batch.feasible_sets_batch(*fargs, variant=3), batch.feasible_sets_batch(*fargs, variant=2, strict=True), equal_nan=True)
         K = batch.controllable_sets_batch(*args[:5], 0.0, sd1, interp, variant=3)
         assert np.array_equal(K, batch.controllable_sets_batch(*args[:5], 0.0, sd1, interp, variant=2, strict=True), equal_nan=True)
+
+
+def test_violated_row_with_zero_normal_is_an_infeasible_stage(gpu, oracle):
+    """A joint that stands still (q' = q'' = 0 along the whole path) with an acceleration range that excludes 0 gives rows
+    (0, 0, c > 0): violated, and not a line.  The reference raises ZeroDivisionError there (cy_seidel_solverwrapper.pyx:290,
+    cdivision=False); here the LP is reported infeasible -- the one deliberate difference -- by every
+    kernel family and by the oracle alike, and the other trajectories of the batch are not affected."""
+    B, d, N = 96, 3, 40
+    data = batch.make_synthetic_batch(B, d, N, seed=77)
+    way = data["waypoints"].copy()
+    hit = np.zeros(B, bool)
+    hit[[0, 5, 17, 63, 64, 95]] = True
+    way[hit, :, 1] = way[hit, :1, 1]                       # joint 1 does not move
+    coef, breaks = batch.spline_coefficients(data["knots"], way)
+    assert np.all(coef[hit][:, :3, :, 1] == 0.0)           # its q', q'' are exactly 0
+    alim = data["alim"].copy()
+    alim[hit, 1, 0], alim[hit, 1, 1] = 0.5, 2.0            # 0 is not an admissible acceleration for it
+    args = (coef, breaks, data["grid"], data["vlim"], alim)
+    want = oracle.solve_batch(*args, None, None)
+    assert (want["status"][hit] != 0).all() and (want["status"][~hit] == 0).all()
+    for kw in (dict(variant=1), dict(variant=2), dict(variant=2, strict=True), dict(variant=3), dict(variant=4), dict()):
+        got = batch.solve_batch(*args, **kw)
+        for k in ("K", "sd2", "u", "status"):
+            assert np.array_equal(got[k], want[k], equal_nan=True), (kw, k)
+        assert np.isnan(got["sd2"][hit]).all() and not np.isnan(got["sd2"][~hit]).any()

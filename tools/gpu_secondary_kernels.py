@@ -67,6 +67,7 @@ def main():
     cases["robust_collocation_16384x7x100"] = lambda: tb.robust_solve_batch(*dv4, [1e-3, 5e-2, 9e-3], interpolation=False)
     cases["robust_with_feasible_sets_16384x7x100"] = lambda: tb.robust_solve_batch(*dv4, [1e-3, 5e-2, 9e-3], want_X=True)
     # dense rows (any canonical-linear constraint list): the standard problem's own rows fed back as arrays
+    cases["constraint_params_65536x7x200"] = lambda: tb.constraint_params_batch(*dv)
     rows = tb.constraint_params_batch(*dv)
     dense = (rows["a"], rows["b"], rows["c"], rows["low"], rows["high"], dv[2][1:] - dv[2][:-1])
     cases["dense_rows_solve_65536x7x200"] = lambda: tb.solve_dense_batch(*dense)

@@ -1254,9 +1254,14 @@ int tpr_constraint_params_batch(const tpr_problem *p, double *a, double *b, doub
     double *dlow = S.out(low, pts * 2), *dhigh = S.out(high, pts * 2), *dxb = S.out(xbound, pts * 2);
     double *dqs = S.out(qs, pts * p->d), *dqss = S.out(qss, pts * p->d);
     if (S.err != hipSuccess) return fail(TPR_E_HIP, hipGetErrorString(S.err));
-    if (pts > 0)
-        hipLaunchKernelGGL(tpr::params_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, stream, A,
+    if (pts > 0) {
+        const unsigned tiles = (unsigned)((p->N + 1 + tpr::kParamsTile - 1) / tpr::kParamsTile);
+        if (tiles > 65535u) return fail(TPR_E_UNSUPPORTED, "tpr_constraint_params_batch: more than 2 M gridpoints");
+        const int tile = (int)((p->N + 1 + tiles - 1) / tiles);
+        const size_t lds = ((size_t)2 * (tpr::kParamsTile + 1) * p->d + tpr::kParamsTile + 2 * p->d) * sizeof(double);
+        hipLaunchKernelGGL(tpr::params_tile_kernel, dim3((unsigned)p->B, tiles), dim3(256), lds, stream, A, tile,
                            da, db, dc, dlow, dhigh, dxb, dqs, dqss);
+    }
     HIP_TRY(S.finish());
     return TPR_E_OK;
 }
