@@ -47,13 +47,14 @@ if __name__ == "__main__":
     total = 0
     for r in range(rounds):
         for B, d, N, seed in ((16384, 7, 60, 1 + 10 * r), (16384, 4, 50, 2 + 10 * r), (16384, 3, 40, 3 + 10 * r), (8192, 8, 48, 4 + 10 * r),
-                              (16384, 5, 70, 5 + 10 * r), (16384, 6, 64, 6 + 10 * r), (8192, 2, 40, 7 + 10 * r), (4096, 12, 40, 8 + 10 * r)):
+                              (16384, 5, 70, 5 + 10 * r), (16384, 6, 64, 6 + 10 * r), (8192, 2, 40, 7 + 10 * r), (4096, 12, 40, 8 + 10 * r),
+                              (8192, 9, 40, 9 + 10 * r), (8192, 10, 36, 10 + 10 * r), (8192, 11, 32, 11 + 10 * r), (8192, 13, 30, 12 + 10 * r)):
             args, j = family(B, d, N, seed)
             full = batch.solve_batch(*args, strict=True)
             total += B
             line = "B %5d d %2d N %3d seed %3d ok %.3f :" % (B, d, N, seed, (full["status"] == 0).mean())
             for variant, sound in ((2, False), (3, False), (2, True), (3, True), (4, False)):
-                if variant == 3 and d > 8:
+                if variant == 3 and d > 13:
                     continue
                 fast = batch.solve_batch(*args, variant=variant, sound=sound)
                 bad = np.zeros(B, dtype=bool)
