@@ -70,6 +70,7 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
         jobs = [(main, os.path.join(tmp, "main.o"), ["-DTPR_CERT_MAX_DOF=%d" % max_dof])]
         for d in range(1, max_dof + 1):
             extra = os.environ.get("TPR_BUILD_CERT_FLAGS_ABOVE_8", "").split() if d > 8 else []  # (compiler experiments)
+            extra += os.environ.get("TPR_BUILD_CERT_FLAGS", "").split()
             jobs.append((os.path.join(CSRC, "tpr_cert_tu.hip"), os.path.join(tmp, "cert%d.o" % d), ["-DTPR_TU_D=%d" % d] + extra))
         for half in (0, 1):  # the robust (conic) kernels: 1..8 dof + the lane kernel, 9..16 dof
             jobs.append((os.path.join(CSRC, "tpr_robust_tu.hip"), os.path.join(tmp, "robust%d.o" % half), ["-DTPR_TU_HALF=%d" % half]))
