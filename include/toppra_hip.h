@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define TPR_MAX_DOF 32      /* generic lane-per-trajectory kernel (rows per LP: nC = 2 + 4*d <= 130)          */
-#define TPR_MAX_DOF_FAST 16 /* rows-across-lanes kernels (auto above 8 dof); 17..32 dof run the generic kernel */
+#define TPR_MAX_DOF_FAST 16 /* rows-across-lanes kernels (auto at 14..16 dof and for mid-size batches); 17..32 dof: family 4 / 1 */
 
 /* tpr_problem.flags */
 #define TPR_HAS_VELOCITY 1      /* JointVelocityConstraint present                             */
@@ -173,7 +173,7 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
 
 /* Replaces ReachabilityAlgorithm.compute_feasible_sets (reachability_algorithm.py:131-164).
  * X [B][N+1][2].  p->variant: 0 = auto (one wave per trajectory for a handful of trajectories, above 16 dof or with
- * p->active; the certified lane kernel from 8192 trajectories up to 8 dof; rows across lanes
+ * p->active; the certified lane kernel from 8192 trajectories up to 13 dof; rows across lanes
  * otherwise), 1 / 2 / 3 / 4 force a kernel family.  TPR_STRICT_SEIDEL / TPR_SOUND_CERTIFICATES as tpr_solve_batch.   */
 int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream);
 
