@@ -161,6 +161,7 @@ def cpu_baseline(data, target_seconds=12.0):
             ts.append(time.perf_counter() - t0)
         c1[label + "_ms"] = float(np.median(ts) * 1e3)
     return {"value": allcore, "unit": "trajectories/s", "cores": cores, "kind": "port",
+            "reference_solver": reference_solver_rate(data, cores, orc),
             "single_thread": {"value": single, "unit": "trajectories/s", "sample": "%d trajectories" % n1},
             "parallel_efficiency": allcore / (cores * single),
             "best_pass": n / best,
@@ -173,6 +174,39 @@ def cpu_baseline(data, target_seconds=12.0):
                       "(C restatement of the reference's seidel path, bit-exact with it) with OpenMP on %d threads (bound, one "
                       "per core: every CPU this container is allowed); per-thread arenas" % (n, reps, total, cores),
             "reference_itself": reference_rate()}
+
+
+def reference_solver_rate(data, cores, orc):
+    """kind "reference", timed in THIS run: the reference's own compiled seidel solver (oracle/_ref, built from the sources
+    where they lie under /root/reference and shipped to the GPU box as a binary) driven by the reference's two passes
+    restated as Python loops (oracle/ref_solver_baseline.py) -- 3 N Python -> Cython crossings per trajectory, as in the
+    reference.  One process, then one process per usable core; the solver passes only (constraint parameters and the
+    wrapper's row build are outside the timed region).  Its results on the sample are compared with the port's."""
+    try:
+        from oracle import ref_solver_baseline as rb
+        if not rb.available():
+            return {"error": "oracle/_ref holds no compiled reference solver (it is built where /root/reference exists)"}
+        n1, per = 384, 256
+        one = rb.time_passes(data, n1, 1)
+        allp = rb.time_passes(data, min(data["coef"].shape[0], per * cores), cores)
+        # the same bits as the port (and therefore as the GPU) on a few trajectories
+        same = True
+        want = orc.solve_batch(data["coef"][:4], data["breaks"], data["grid"], data["vlim"][:4], data["alim"][:4], nthreads=1)
+        for k in range(4):
+            vel, acc = rb.constraint_tuples(data["coef"][k], data["breaks"], data["grid"], data["vlim"][k], data["alim"][k])
+            w = rb.make_wrapper([rb.PrecomputedConstraint(vel, False), rb.PrecomputedConstraint(acc, True)], None, data["grid"])
+            sdd, sd, K = rb.parameterization(w, 0.0, 0.0)
+            same &= sd is not None and bool(np.array_equal(sd, np.sqrt(want["sd2"][k])) and np.array_equal(sdd, want["u"][k]) and np.array_equal(K, want["K"][k]))
+        return {"value": allp["trajectories_per_s"], "unit": "trajectories/s", "cores": cores, "kind": "reference",
+                "single_process": {"value": one["trajectories_per_s"], "sample": "%d trajectories" % n1},
+                "parallel_efficiency": allp["trajectories_per_s"] / (cores * one["trajectories_per_s"]),
+                "identical_bits_to_the_port_on_4_trajectories": same,
+                "sample": "first %d trajectories of the rank-0 batch on %d processes (%.2f s of solver passes in the slowest one): the "
+                          "reference's compiled cy_seidel_solverwrapper.seidelWrapper (oracle/_ref), solve_lp1d=True, under the two passes "
+                          "of TOPPRA.compute_parameterization restated in Python (reachability_algorithm.py:166-238, 240-376); "
+                          "compute_constraint_params and the wrapper's construction are not timed" % (allp["trajectories"], cores, allp["seconds"])}
+    except Exception as exc:  # noqa: BLE001  (a measurement leg must not take the bench line down)
+        return {"error": repr(exc)}
 
 
 def reference_rate():
