@@ -143,6 +143,23 @@ def parameterization(w, sd_start, sd_end):
     return us, np.sqrt(xs), K
 
 
+def feasible_sets(w):
+    """reachability_algorithm.py:131-164 (CVXPY_MAXX = 10000: constants.py)."""
+    maxx = 10000.0
+    N = w.get_no_stages()
+    nV = w.get_no_vars()
+    g_lower = np.zeros(nV)
+    g_lower[0], g_lower[1] = 1e-9, 1
+    X = np.zeros((N + 1, 2))
+    w.setup_solver()
+    for i in range(N + 1):
+        X[i, 0] = w.solve_stagewise_optim(i, None, g_lower, -maxx, maxx, -maxx, maxx)[1]
+        X[i, 1] = w.solve_stagewise_optim(i, None, -g_lower, -maxx, maxx, -maxx, maxx)[1]
+    w.close_solver()
+    X[X[:, 0] < 0, 0] = 0
+    return X
+
+
 class PrecomputedConstraint:
     """What seidelWrapper.__init__ asks of a constraint (cy_seidel_solverwrapper.pyx:437-455), answered from a stored tuple
     (picklable: the worker processes rebuild their wrappers from these without touching a GPU)."""

@@ -264,3 +264,31 @@ def test_against_the_references_own_compiled_solver(gpu, d, N, seed):
             assert np.array_equal(got["sd"][k], sd, equal_nan=True), (kw, k, "sd")
             if not np.isnan(sd).any():
                 assert np.array_equal(got["u"][k], sdd), (kw, k, "u")
+
+
+@pytest.mark.parametrize("d,N,seed", [(7, 80, 21), (4, 30, 22), (11, 40, 23)])
+def test_sets_against_the_references_own_compiled_solver(gpu, d, N, seed):
+    """compute_feasible_sets and compute_controllable_sets(sdmin, sdmax) of the reference's compiled solver under the
+    reference's loops (oracle/ref_solver_baseline.py) against the HIP entries, every family, bit for bit."""
+    from oracle import ref_solver_baseline as rb
+    if not rb.available():
+        pytest.skip("oracle/_ref holds no compiled reference solver (built where /root/reference exists)")
+    B = 16
+    data = batch.make_synthetic_batch(B, d, N, seed=seed)
+    rng = np.random.default_rng(seed)
+    coef = data["coef"] * np.where(rng.random((B, 1, 1, 1)) < 0.5, 1.0, 10.0 ** rng.uniform(-4, 0.3, size=(B, 1, 1, 1)))
+    lo = np.round(0.1 * rng.random(B) * 1024) / 1024
+    hi = lo + np.round(0.3 * rng.random(B) * 1024) / 1024
+    Xr, Kr = [], []
+    for k in range(B):
+        vel, acc = rb.constraint_tuples(coef[k], data["breaks"], data["grid"], data["vlim"][k], data["alim"][k])
+        cons = [rb.PrecomputedConstraint(vel, False), rb.PrecomputedConstraint(acc, True)]
+        Xr.append(rb.feasible_sets(rb.make_wrapper(cons, None, data["grid"])))
+        Kr.append(rb.controllable_sets(rb.make_wrapper(cons, None, data["grid"]), float(lo[k]), float(hi[k])))
+    args = (coef, data["breaks"], data["grid"], data["vlim"], data["alim"])
+    for kw in [dict(variant=1), dict(variant=2), dict(variant=4), dict()] + ([dict(variant=3)] if d <= 13 else []):
+        X = batch.feasible_sets_batch(*args, True, **kw)
+        K = batch.controllable_sets_batch(*args, lo, hi, True, **kw)
+        for k in range(B):
+            assert np.array_equal(X[k], Xr[k], equal_nan=True), (kw, k, "X")
+            assert np.array_equal(K[k], Kr[k], equal_nan=True), (kw, k, "K")
