@@ -124,8 +124,10 @@ struct Runner {
                 if (g_legacy) tpr::cert_propose2<D, 1>(S, -1e-9, 1.0, dn0, dn1, dn0 != dn1, false, nmax, up_p, up_q, up_ok, prow, qrow);
                 else tpr::cert_propose_sound<D, 1>(S, -1e-9, 1.0, dn0, dn1, dn0 != dn1, nmax, up_p, up_q, up_ok, prow, qrow);
                 const int why = tpr::tpr_cert_why;
-                bool need_u = !tpr::cert_pair_rows<D, 1, false>(S, -1e-9, 1.0, up_p, up_q, nok & up_ok, prow[0], prow[1], prow[2],
-                                                                 qrow[0], qrow[1], qrow[2], dn0, dn1, nmax, su);
+                bool need_u = g_legacy ? !tpr::cert_pair_rows<D, 1, false, false>(S, -1e-9, 1.0, up_p, up_q, nok & up_ok, prow[0], prow[1], prow[2],
+                                                                                  qrow[0], qrow[1], qrow[2], dn0, dn1, nmax, su)
+                                       : !tpr::cert_pair_rows<D, 1, false, true>(S, -1e-9, 1.0, up_p, up_q, nok & up_ok, prow[0], prow[1], prow[2],
+                                                                                 qrow[0], qrow[1], qrow[2], dn0, dn1, nmax, su);
                 tpr::tpr_cert_why = 0;
                 bool need_l = g_legacy ? !tpr::cert_lower<D, 1>(S, nok, nmax, sl) : !tpr::cert_lower_sound<D, 1>(S, nok, nmax, up0, up1, sl);
                 if (need_l && !(kn0 == kn1)) G.why_low[tpr::tpr_cert_why & 15]++;
@@ -193,8 +195,8 @@ struct Runner {
                 tpr::tpr_cert_why = 0;
                 tpr::cert_propose_sound<D, 1>(S, 1e-9, 1.0, dn0, dn1, dn0 != dn1, nmax, up_p, up_q, up_ok, prow, qrow);
                 const int why_u = tpr::tpr_cert_why;
-                const bool need_u = !tpr::cert_pair_rows<D, 1, false>(S, 1e-9, 1.0, up_p, up_q, nok & up_ok, prow[0], prow[1], prow[2],
-                                                                       qrow[0], qrow[1], qrow[2], dn0, dn1, nmax, su);
+                const bool need_u = !tpr::cert_pair_rows<D, 1, false, true>(S, 1e-9, 1.0, up_p, up_q, nok & up_ok, prow[0], prow[1], prow[2],
+                                                                             qrow[0], qrow[1], qrow[2], dn0, dn1, nmax, su);
                 if (need_u) G.why_fu[why_u & 15]++;
                 tpr::tpr_cert_why = 0;
                 const bool need_l = !tpr::cert_lower_sound<D, 1, false>(S, nok, nmax, up0, up1, sl);
