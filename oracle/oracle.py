@@ -89,6 +89,8 @@ def lib():
         L.orc_wrapper_nC.argtypes = [C.c_void_p]
         L.orc_wrapper_active.restype = None
         L.orc_wrapper_active.argtypes = [C.c_void_p, lp]
+        L.orc_wrapper_set_active.restype = None
+        L.orc_wrapper_set_active.argtypes = [C.c_void_p, lp]
         _lib = L
     return _lib
 
@@ -196,6 +198,11 @@ class Wrapper:
         out = np.zeros(4, dtype=np.int64)
         lib().orc_wrapper_active(self._h, out.ctypes.data_as(C.POINTER(C.c_long)))
         return out
+
+    def set_active(self, state):
+        """Seed the warm-start state (active_c_up[0..1], active_c_down[0..1]) as earlier passes on the instance would have."""
+        st = np.ascontiguousarray(state, dtype=np.int64)
+        lib().orc_wrapper_set_active(self._h, st.ctypes.data_as(C.POINTER(C.c_long)))
 
     def solve_stagewise_optim(self, i, H, g, x_min, x_max, x_next_min, x_next_max):
         g = _f64(g)

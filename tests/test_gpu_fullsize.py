@@ -332,3 +332,84 @@ def test_concurrent_rows_and_sliver_pivots_are_bit_exact(gpu, B, d, N, seed):
             bad |= ~same.reshape(B, -1).all(axis=1)
         assert bad.sum() == 0, (variant, int(bad.sum()), np.flatnonzero(bad)[:4])
         assert np.array_equal(batch.solve_batch(*args, variant=variant, sound=True)["K"], got["K"], equal_nan=True)  # the flag is a no-op
+    # ... and `full` is not only the GPU's own full iteration: the first 512 trajectories against the CPU restatement of the
+    # reference (oracle/, pinned to the reference's compiled solver), failures of the reference included
+    from oracle import oracle as orc
+    m = 512
+    ref = orc.solve_batch(coef[:m], data["breaks"], grid, data["vlim"][:m], alim[:m], None, sd1[:m], nthreads=0)
+    assert np.array_equal(ref["status"], full["status"][:m])
+    for k in ("K", "sd2", "u"):
+        assert np.array_equal(ref[k], full[k][:m], equal_nan=True), k
+
+
+def _tool(name):
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("B,d,N,seed", [(768, 7, 60, 101), (768, 4, 50, 102), (512, 12, 40, 105)])
+def test_sliver_family_against_the_references_own_compiled_solver(gpu, B, d, N, seed):
+    """The one place the reference is known to FAIL -- an intermediate sliver pivot ends its run "infeasible" on an LP that
+    has an optimum (cy_seidel_solverwrapper.pyx:127,:342,:353-355) -- against the reference ITSELF: its compiled
+    cy_seidel_solverwrapper (oracle/_ref) under the reference's two passes (oracle/ref_solver_baseline.py), every kernel
+    family and the default choice, K, sd, u and the failures bit for bit (a cut of tools/gpu_vs_reference_solver.py)."""
+    from oracle import ref_solver_baseline as rb
+    if not rb.available():
+        pytest.skip("oracle/_ref holds no compiled reference solver (built where /root/reference exists)")
+    (coef, breaks, grid, vlim, alim, sd0, sd1), _ = _tool("gpu_sliver_hunt").family(B, d, N, seed)
+    sd1 = np.round(np.asarray(sd1) * 1024) / 1024  # exact squares: ** in the reference's passes, sd * sd on the device
+    ref = []
+    for k in range(B):
+        vel, acc = rb.constraint_tuples(coef[k], breaks, grid, vlim[k], alim[k])
+        w = rb.make_wrapper([rb.PrecomputedConstraint(vel, False), rb.PrecomputedConstraint(acc, True)], None, grid)
+        ref.append(rb.parameterization(w, 0.0, float(sd1[k])))
+    nfail = sum(1 for x in ref if x[1] is None or np.isnan(x[1]).any())
+    assert 0.05 * B < nfail < B  # the family does make the reference fail
+    for variant in (0, 2, 3, 4):
+        got = batch.solve_batch(coef, breaks, grid, vlim, alim, sd0, sd1, want_sd=True, variant=variant)
+        for k in range(B):
+            sdd, sd, K = ref[k]
+            if sd is None:
+                assert got["status"][k] != 0, (variant, k)
+                continue
+            assert np.array_equal(got["K"][k], K, equal_nan=True), (variant, k, "K")
+            assert np.array_equal(got["sd"][k], sd, equal_nan=True), (variant, k, "sd")
+            if not np.isnan(sd).any():
+                assert np.array_equal(got["u"][k], sdd), (variant, k, "u")
+
+
+@pytest.mark.parametrize("B,d,N,seed", [(1024, 7, 60, 31), (1024, 4, 50, 32), (512, 9, 40, 33)])
+def test_a_valid_warm_start_of_the_lower_bound_lp_on_the_sliver_family(gpu, oracle, B, d, N, seed):
+    """the lower-bound certificates follow the reference's COLD run.  With two distinct structural rows in
+    the wrapper's active_c_up -- left by an earlier pass on the instance, carried in through tpr_problem.active -- the
+    reference visits [up1, up0, ...] first: another trace, on which an intermediate sliver pivot may end its run where the
+    cold run does not.  Kernel family 4 (the one that carries the state) must then iterate instead of certifying; here the
+    state is seeded with random structural pairs on the sliver family and compared, state out included, with the CPU
+    restatement's wrapper objects seeded the same way."""
+    (coef, breaks, grid, vlim, alim, sd0, sd1), _ = _tool("gpu_sliver_hunt").family(B, d, N, seed)
+    rng = np.random.default_rng(seed)
+    nC = 2 + 4 * d
+    active = np.zeros((B, 4), dtype=np.int32)
+    active[:, 0] = rng.integers(0, nC, size=B)
+    active[:, 1] = (active[:, 0] + rng.integers(1, nC, size=B)) % nC   # distinct structural rows: a valid warm start
+    keep = rng.random(B) < 0.25
+    active[keep, 2] = rng.integers(2, nC, size=keep.sum())              # some with a seeded upper-bound pair as well
+    active[keep, 3] = (active[keep, 2] + 1 + rng.integers(0, nC - 3, size=keep.sum())) % nC
+    seeded = active.copy()
+    for variant in (4, 0):
+        state = seeded.copy()
+        got = batch.solve_batch(coef, breaks, grid, vlim, alim, sd0, sd1, active=state, variant=variant)
+        for b in range(0, B, 2):
+            w = oracle.Wrapper(coef[b], breaks, grid, vlim[b], alim[b])
+            w.set_active(seeded[b])
+            st, sdd, sd, xs, K = w.compute_parameterization(0.0, float(sd1[b]))
+            assert st == got["status"][b], (variant, b)
+            assert np.array_equal(K, got["K"][b], equal_nan=True), (variant, b, "K")
+            if st == 0:
+                assert np.array_equal(xs, got["sd2"][b]) and np.array_equal(sdd, got["u"][b]), (variant, b)
+            assert np.array_equal(w.active(), state[b]), (variant, b, w.active(), state[b])
