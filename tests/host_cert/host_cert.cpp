@@ -47,6 +47,7 @@ struct Stats {
 static Stats G;
 static int g_verbose = 0;
 static int g_legacy = 0;  // 1: the round-2/3 FAST certificates (cert_propose2 / cert_lower / cert_equality) instead of the sound ones
+static int g_minform = 0; // 1: the slides' verdicts as a running minimum (the TOPPRAsd kernels' form) instead of sign bits (the other kernels')
 
 static bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b) || (isnan(a) && isnan(b)); }
 
@@ -122,14 +123,16 @@ struct Runner {
                 const int wdn0 = dn0, wdn1 = dn1;
                 tpr::tpr_cert_why = 0;
                 if (g_legacy) tpr::cert_propose2<D, 1>(S, -1e-9, 1.0, dn0, dn1, dn0 != dn1, false, nmax, up_p, up_q, up_ok, prow, qrow);
-                else tpr::cert_propose_sound<D, 1>(S, -1e-9, 1.0, dn0, dn1, dn0 != dn1, nmax, up_p, up_q, up_ok, prow, qrow);
+                else if (g_minform) tpr::cert_propose_sound<D, 1, 0, false>(S, -1e-9, 1.0, dn0, dn1, dn0 != dn1, nmax, up_p, up_q, up_ok, prow, qrow);
+                else tpr::cert_propose_sound<D, 1, 0, true>(S, -1e-9, 1.0, dn0, dn1, dn0 != dn1, nmax, up_p, up_q, up_ok, prow, qrow);
                 const int why = tpr::tpr_cert_why;
                 bool need_u = g_legacy ? !tpr::cert_pair_rows<D, 1, false, false>(S, -1e-9, 1.0, up_p, up_q, nok & up_ok, prow[0], prow[1], prow[2],
                                                                                   qrow[0], qrow[1], qrow[2], dn0, dn1, nmax, su)
                                        : !tpr::cert_pair_rows<D, 1, false, true>(S, -1e-9, 1.0, up_p, up_q, nok & up_ok, prow[0], prow[1], prow[2],
                                                                                  qrow[0], qrow[1], qrow[2], dn0, dn1, nmax, su);
                 tpr::tpr_cert_why = 0;
-                bool need_l = g_legacy ? !tpr::cert_lower<D, 1>(S, nok, nmax, sl) : !tpr::cert_lower_sound<D, 1>(S, nok, nmax, up0, up1, sl);
+                bool need_l = g_legacy ? !tpr::cert_lower<D, 1>(S, nok, nmax, sl)
+                                       : (g_minform ? !tpr::cert_lower_sound<D, 1, true, false>(S, nok, nmax, up0, up1, sl) : !tpr::cert_lower_sound<D, 1, true, true>(S, nok, nmax, up0, up1, sl));
                 if (need_l && !(kn0 == kn1)) G.why_low[tpr::tpr_cert_why & 15]++;
                 const bool eq = kn0 == kn1;
                 if (eq) {
@@ -193,13 +196,14 @@ struct Runner {
                 tpr::Lp2dOut su, sl;
                 int up_p, up_q; bool up_ok; double prow[3], qrow[3];
                 tpr::tpr_cert_why = 0;
-                tpr::cert_propose_sound<D, 1>(S, 1e-9, 1.0, dn0, dn1, dn0 != dn1, nmax, up_p, up_q, up_ok, prow, qrow);
+                if (g_minform) tpr::cert_propose_sound<D, 1, 0, false>(S, 1e-9, 1.0, dn0, dn1, dn0 != dn1, nmax, up_p, up_q, up_ok, prow, qrow);
+                else tpr::cert_propose_sound<D, 1, 0, true>(S, 1e-9, 1.0, dn0, dn1, dn0 != dn1, nmax, up_p, up_q, up_ok, prow, qrow);
                 const int why_u = tpr::tpr_cert_why;
                 const bool need_u = !tpr::cert_pair_rows<D, 1, false, true>(S, 1e-9, 1.0, up_p, up_q, nok & up_ok, prow[0], prow[1], prow[2],
                                                                              qrow[0], qrow[1], qrow[2], dn0, dn1, nmax, su);
                 if (need_u) G.why_fu[why_u & 15]++;
                 tpr::tpr_cert_why = 0;
-                const bool need_l = !tpr::cert_lower_sound<D, 1, false>(S, nok, nmax, up0, up1, sl);
+                const bool need_l = g_minform ? !tpr::cert_lower_sound<D, 1, false, false>(S, nok, nmax, up0, up1, sl) : !tpr::cert_lower_sound<D, 1, false, true>(S, nok, nmax, up0, up1, sl);
                 if (need_l) G.why_fl[tpr::tpr_cert_why & 15]++;
                 // reachability_algorithm.py:149-157: min x first (g = (1e-9, 1): state active_c_up), then max x
                 const double g_lo[2] = {1e-9, 1}, g_hi[2] = {-1e-9, -1};
@@ -248,7 +252,8 @@ int main(int argc, char **argv) {
     int hdr[8];
     if (std::fread(hdr, sizeof(int), 8, f) != 8) return 2;
     const int B = hdr[0], d = hdr[1], nseg = hdr[2], N = hdr[3], flags = hdr[4], mode = hdr[5], has_sd_end = hdr[6];
-    g_legacy = hdr[7];
+    g_legacy = hdr[7] & 1;
+    g_minform = (hdr[7] >> 1) & 1;
     std::vector<double> coef((size_t)B * 4 * nseg * d), breaks(nseg + 1), grid(N + 1), vlim((size_t)B * 2 * d), alim((size_t)B * 2 * d), sd_end(B, 0.0);
     size_t got = std::fread(coef.data(), 8, coef.size(), f) + std::fread(breaks.data(), 8, breaks.size(), f) + std::fread(grid.data(), 8, grid.size(), f) +
                  std::fread(vlim.data(), 8, vlim.size(), f) + std::fread(alim.data(), 8, alim.size(), f);

@@ -39,6 +39,18 @@ def test_certificates_return_the_references_bits(harness, family, seed, B, min_u
         assert res["eq_upper_cert"] + res["eq_lower_cert"] >= 1.8 * res["eq_upper"], res
 
 
+@pytest.mark.parametrize("family,seed,B", [("natural", 0, 24), ("sliver", 0, 64), ("lower_ties", 5, 48), ("feasible", 0, 24)])
+def test_the_minimum_form_of_the_slides(harness, family, seed, B):
+    """The slides fold their verdicts into sign bits (every kernel but TOPPRAsd's) or into a running minimum (TOPPRAsd's
+    instantiations: tpr_cert_lane.hip.inc, cert_slide_visit): the tests above run the sign-bit form, this one the other."""
+    (coef, breaks, grid, vlim, alim, sd_end, flags, mode), _ = hunt.workloads(family, B, seed)
+    res, rc = hunt.run(coef, breaks, grid, vlim, alim, sd_end, flags, mode, minform=True)
+    assert res["mismatch"] == 0 and res["ref_failed_cert_answered"] == 0 and rc == 0, res
+    both, _ = hunt.run(coef, breaks, grid, vlim, alim, sd_end, flags, mode)
+    for k in ("upper_cert", "lower_cert", "feas_upper_cert", "feas_lower_cert"):
+        assert abs(both[k] - res[k]) <= 2, (k, both[k], res[k])  # (an exact tie at a tolerance boundary is the only difference)
+
+
 @pytest.mark.parametrize("seed", [0, 2])
 def test_feasible_set_certificates(harness, seed):
     (coef, breaks, grid, vlim, alim, sd_end, flags, mode), _ = hunt.workloads("feasible", 32, seed)

@@ -37,12 +37,12 @@ def build(force=False):
     return EXE
 
 
-def run(coef, breaks, grid, vlim, alim, sd_end=None, flags=FLAG_VEL | FLAG_ACC | FLAG_INTERP, mode=0, verbose=False, legacy=False):
+def run(coef, breaks, grid, vlim, alim, sd_end=None, flags=FLAG_VEL | FLAG_ACC | FLAG_INTERP, mode=0, verbose=False, legacy=False, minform=False):
     build()
     B, _, nseg, d = coef.shape
     N = len(grid) - 1
     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
-        np.array([B, d, nseg, N, flags, mode, 0 if sd_end is None else 1, 1 if legacy else 0], dtype=np.int32).tofile(f)
+        np.array([B, d, nseg, N, flags, mode, 0 if sd_end is None else 1, (1 if legacy else 0) | (2 if minform else 0)], dtype=np.int32).tofile(f)
         for arr in (coef, breaks, grid, vlim, alim):
             np.ascontiguousarray(arr, dtype=np.float64).tofile(f)
         if sd_end is not None:
@@ -158,6 +158,7 @@ def main():
     opts = dict((a[2:].split("=") + ["1"])[:2] for a in sys.argv[1:] if a.startswith("--"))
     rounds, B, start = int(opts.get("rounds", 1)), int(opts.get("B", 256)), int(opts.get("start", 0))
     legacy = "legacy" in opts
+    minform = "minform" in opts  # the slides' verdicts as a running minimum (the TOPPRAsd kernels' form) instead of sign bits
     fams = args or ["natural", "scaled", "tight", "boundary", "collocation", "acc_only", "sliver", "parallel", "feasible"]
     build(force=start == 0)
     bad = 0
@@ -165,7 +166,7 @@ def main():
         for fam in fams:
             for seed in range(11 * r, 11 * r + 11):
                 (coef, breaks, grid, vlim, alim, sd_end, flags, mode), (d, N) = workloads(fam, B, seed)
-                res, rc = run(coef, breaks, grid, vlim, alim, sd_end, flags, mode, legacy=legacy)
+                res, rc = run(coef, breaks, grid, vlim, alim, sd_end, flags, mode, legacy=legacy, minform=minform)
                 res["family"] = fam
                 res["seed"] = seed
                 print(json.dumps(res), flush=True)
