@@ -1,0 +1,78 @@
+"""The certified lane kernels' resource usage, read from the built library's own code objects (tools/kernel_resources.py: the
+AMDGPU metadata notes + a disassembly of the headline instantiations; no GPU, no recompile) against committed ceilings.
+
+Why this is a test (DESIGN.md sections 3.2 and 9): these kernels sit at the edge of the register file, and twice a
+value-identical spelling of one expression decided between a kernel without scratch and one with 1.4 - 2.4 KB of it per lane
+(a conditionally-needed load that the compiler sinks into divergent regions: 5 x slower) -- and the same regions were the
+trigger of round 3's wrong feasible sets at 11 / 13 dof.  The workaround in the source (CertStage::fetch: both loads on every
+path, merged under an opaque mask) is invisible to a reader of the results; a toolchain that defeats it must fail here."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.fixture(scope="module")
+def resources():
+    import kernel_resources as kr
+    from toppra_amd import build
+    build.build()
+    return kr, kr.kernels()
+
+
+def _family3(ks):
+    out = {}
+    for name, r in ks.items():
+        m = re.match(r"_ZN3tpr\d+(cert_solve_kernel|cert_feasible_kernel)ILi(\d+)E", name)
+        if m:
+            out.setdefault((m.group(1), int(m.group(2))), []).append(r)
+    return out
+
+
+def test_scratch_lds_and_registers_of_the_certified_lane_kernels(resources):
+    """Per dof, over every instantiation (sd output, grid in LDS, discretisation, TOPPRAsd): no scratch at all up to 8 dof, at
+    most 512 B per lane at 9..13 dof (round 5 as built: 28 .. 448 B; the failure mode is 1.4 KB and more); LDS small enough for
+    four blocks per CU (one wave per SIMD) -- 160 KB / 4; and a register count that still fits one wave per SIMD."""
+    kr, ks = resources
+    fam = _family3(ks)
+    assert {d for (_, d) in fam} == set(range(1, 14)), sorted(fam)
+    for (kernel, d), rs in sorted(fam.items()):
+        scratch = max(r["scratch"] for r in rs)
+        lds = max(r["lds"] for r in rs)
+        regs = max(r["vgpr"] for r in rs)
+        assert scratch <= (0 if d <= 8 else 512), (kernel, d, "scratch bytes per lane", scratch)
+        assert lds <= 160 * 1024 // 4, (kernel, d, "LDS bytes per block", lds)
+        assert regs <= 512, (kernel, d, "vector + accumulator registers", regs)
+
+
+# (dof, grid in LDS): instructions and divergent-region branches (s_cbranch_exec*) of cert_solve_kernel<dof, 64, no sd output, ...,
+# Interpolation, sound, not TOPPRAsd> as built in round 5, with 5 % / 10 % of headroom.  Round 4's pathological fetch took the 9-dof
+# kernel from 129 to 172 such branches.
+CEILINGS = {(7, 1): (10884, 123), (9, 0): (13329, 133), (12, 0): (17202, 155), (13, 0): (17652, 159)}
+
+
+@pytest.mark.parametrize("d,gl", sorted(CEILINGS))
+def test_headline_instantiations_keep_their_shape(resources, d, gl):
+    kr, ks = resources
+    sym = "_ZN3tpr17cert_solve_kernelILi%dELi64ELb0ELb%dELb1ELb1ELb0EEEvNS_9GroupArgsE" % (d, gl)
+    assert sym in ks, sym
+    lib = os.path.join(ROOT, "toppra_amd", "libtoppra_hip.so")
+    obj = next(o for o in kr.code_objects(lib) if sym.encode() in o)
+    with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+        f.write(obj)
+    try:
+        text = subprocess.run([OBJDUMP, "-d", "--disassemble-symbols=" + sym, f.name], capture_output=True, text=True).stdout
+    finally:
+        os.unlink(f.name)
+    insts = sum(1 for line in text.splitlines() if re.match(r"^\s+(s_|v_|ds_|global_|buffer_|scratch_|flat_)", line))
+    branches = text.count("s_cbranch_exec")
+    n0, b0 = CEILINGS[(d, gl)]
+    assert 0.5 * n0 < insts <= 1.05 * n0, (d, gl, "instructions", insts, n0)
+    assert branches <= 1.10 * b0 + 1, (d, gl, "s_cbranch_exec*", branches, b0)
