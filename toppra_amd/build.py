@@ -77,27 +77,37 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
         jobs.append((os.path.join(CSRC, "tpr_dense_tu.hip"), os.path.join(tmp, "dense.o"), []))  # dense rows: any constraint list
         jobs.sort(key=lambda j: 0 if ("robust" in j[1] or "main" in j[1] or "dense" in j[1]) else 1)  # the longest units first
 
-        # Object cache (build/objcache, git-ignored): an object is reused when its source, every file of csrc/ + the header
-        # and its flags are unchanged.  Development shortcut: TPR_BUILD_ONLY_CERT_DOFS="7 12" recompiles only those dofs of
-        # kernel family 3 and takes the other dofs' objects from the cache even when they are stale (never for a release
-        # build: __graft_entry__.build() does not set it).
+        # Object cache (git-ignored): an object is reused when its source, every file of csrc/ + the header, its flags AND the
+        # compiler (`hipcc --version`) are unchanged.  File names are <unit>_<flags hash>_<sources hash>.o; writes go through a
+        # temporary file + os.replace, so that concurrent builders (several ranks, pytest workers) never link a half-written
+        # object.  Development shortcut: TPR_BUILD_ONLY_CERT_DOFS="7 12" recompiles only those dofs of kernel family 3 and takes
+        # the other dofs' objects from the cache even when their SOURCES are stale -- never with other flags (the tolerance
+        # build's -ffp-contract=fast objects carry another flags hash), and never for a release build (__graft_entry__.build()
+        # does not set it).
         import hashlib
-        cache = os.path.join(HERE, "..", "build", "objcache")
+        cache = os.environ.get("TPR_BUILD_CACHE") or os.path.join(HERE, "..", "build", "objcache")
+        if not os.environ.get("TPR_BUILD_CACHE") and (not os.access(os.path.abspath(os.path.join(HERE, "..")), os.W_OK) or "site-packages" in HERE):
+            cache = os.path.join(os.path.expanduser("~"), ".cache", "toppra_amd", "objcache")  # an installed package: a user cache
         os.makedirs(cache, exist_ok=True)
         dep_hash = hashlib.sha256()
         for path in sorted(deps()):
             with open(path, "rb") as fh:
                 dep_hash.update(fh.read())
+        try:
+            cc_id = subprocess.run([cc, "--version"], capture_output=True, text=True).stdout
+        except OSError:
+            cc_id = cc
         only = os.environ.get("TPR_BUILD_ONLY_CERT_DOFS", "").split()
 
         def run(job):
             src, obj, extra = job
-            key = hashlib.sha256((dep_hash.hexdigest() + " ".join(cflags + dflags + extra) + os.path.basename(src)).encode()).hexdigest()[:24]
+            fkey = hashlib.sha256((cc_id + " ".join(cflags + dflags + extra)).encode()).hexdigest()[:12]
+            skey = hashlib.sha256((dep_hash.hexdigest() + os.path.basename(src)).encode()).hexdigest()[:12]
             name = os.path.basename(obj)[:-2]
-            cached = os.path.join(cache, "%s_%s.o" % (name, key))
+            cached = os.path.join(cache, "%s_%s_%s.o" % (name, fkey, skey))
             stale_ok = only and name.startswith("cert") and name[4:] not in only
             if stale_ok and not os.path.exists(cached):
-                olds = sorted((f for f in os.listdir(cache) if f.startswith(name + "_")), key=lambda f: os.path.getmtime(os.path.join(cache, f)))
+                olds = sorted((f for f in os.listdir(cache) if f.startswith("%s_%s_" % (name, fkey))), key=lambda f: os.path.getmtime(os.path.join(cache, f)))
                 if olds:
                     cached = os.path.join(cache, olds[-1])
             if os.path.exists(cached):
@@ -107,10 +117,15 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd, cwd=CSRC)
-            for f in os.listdir(cache):  # one object per unit
-                if f.startswith(name + "_"):
-                    os.remove(os.path.join(cache, f))
-            shutil.copyfile(obj, cached)
+            for f in os.listdir(cache):  # one object per unit and flag set
+                if f.startswith("%s_%s_" % (name, fkey)):
+                    try:
+                        os.remove(os.path.join(cache, f))
+                    except OSError:
+                        pass
+            tmp_obj = "%s.%d.tmp" % (cached, os.getpid())
+            shutil.copyfile(obj, tmp_obj)
+            os.replace(tmp_obj, cached)
             return obj
 
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:

@@ -14,21 +14,14 @@
 #include "tpr_cert.hip.inc"
 
 #ifndef TPR_TU_D
-#error "compile with -DTPR_TU_D=<dof 1..8>"
+#error "compile with -DTPR_TU_D=<dof 1..13>"
 #endif
 
-// The sound certificate mode is instantiated up to 8 dof only.  Above that the kernels sit at the limit of the register file
-// (512 registers, ~100 scalar registers spilled into vector lanes, ~150 vector registers spilled to scratch) and some
-// SOUND instantiations are miscompiled by this toolchain (ROCm 7.2 hipcc): 9 dof with the pre-slim layout returned lower
-// bounds off in the last bits on 0.9 % of an irregular batch; with the slim layout cert_feasible_kernel<11 | 13,
-// Interpolation, sound> runs 7 x longer than it should and stores nothing at all -- one trajectory, two stages reproduce
-// it -- while either of two unrelated source perturbations (fast proposal + sound batches, or the reverse) makes the same
-// instantiation bit-exact, as are the neighbouring dofs, Collocation, and every fast instantiation (DESIGN.md section
-// 3.2).  Sound requests above 8 dof are served by the rows-across-lanes kernels, whose sound mode is bit-exact there.
-// -2 = not instantiated.
-// Round 4: the certificates follow the reference's whole pivot trace (tpr_cert_lane.hip.inc: cert_propose_sound & co) -- the
-// only mode of the product; TPR_SOUND_CERTIFICATES is accepted and changes nothing.  The round-2/3 "fast" certificates
-// (last pivot only) survive in the opt-in tolerance measurement build.
+// The certificates follow the reference's whole pivot trace (tpr_cert_lane.hip.inc: cert_propose_sound & co) -- the only mode
+// of the product at every dof this file is compiled for (1..13; slim blocks above 8 dof); TPR_SOUND_CERTIFICATES is accepted
+// and changes nothing.  The round-2/3 "fast" certificates (last pivot only) survive in the opt-in tolerance measurement
+// build.  History of the 9..13-dof instantiations (round 3: not shipped sound; round 4: one conditionally-needed load in
+// CertStage::fetch): DESIGN.md sections 3.2 and 9; tests/test_kernel_resources.py pins their scratch and branch counts.
 #ifdef TPR_TOLERANCE_MODE
 constexpr bool kSoundKernels = false;
 #else
