@@ -148,6 +148,17 @@ def build_tolerance(out=None, verbose=False):
     return _compile_and_link(target, flags, ["TPR_TOLERANCE_MODE"], verbose, single_tu=False, cert_max_dof=min(CERT_MAX_DOF, 8))
 
 
+def build_sound_tolerance(out=None, verbose=False):
+    """The second opt-in measurement build (round 5): the product's SOUND, trace-following certificates with tolerance
+    arithmetic in what they return (-DTPR_SOUND_TOLERANCE: the verified vertex from a reciprocal estimate instead of the
+    reference's last-pivot formulas and their cross-product guard, reciprocal-based quotients in the forward 1-variable LP) --
+    same compiler flags as the product, so the cooperative batches' full iteration stays the reference's arithmetic.  It
+    separates what SOUNDNESS costs (kept) from what BIT-EXACTNESS costs (dropped); bench.py reports it beside
+    `tolerance_build`.  NOT the product library; nothing loads it by default."""
+    target = os.path.abspath(out) if out else os.path.join(HERE, "libtoppra_hip_stol.so")
+    return _compile_and_link(target, FLAGS, ["TPR_SOUND_TOLERANCE"], verbose, single_tu=False, cert_max_dof=min(CERT_MAX_DOF, 8))
+
+
 def build(force=False, verbose=False, defines=(), out=None):
     """Build the library.  ``defines`` / ``out`` produce an instrumented copy next to the product one
     (e.g. defines=("TPR_CERT_TIMING", "TPR_CERT_DEV"), used by tools/gpu_cert_phases.py via
@@ -172,6 +183,9 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     if "--tolerance" in args:
         print(build_tolerance(verbose=True))
+        sys.exit(0)
+    if "--sound-tolerance" in args:
+        print(build_sound_tolerance(verbose=True))
         sys.exit(0)
     defs = [a[2:] for a in args if a.startswith("-D")]
     outs = [a.split("=", 1)[1] for a in args if a.startswith("--out=")]
