@@ -343,7 +343,7 @@ def tolerance_probe(B, d, N, seed, sd2, status, libname="libtoppra_hip_tol.so", 
                     "arithmetic FMA-free with correctly rounded divisions; this build certifies the final vertex only -- round 3's "
                     "certificates, which return an optimum where a sliver pivot ends the reference's run -- and returns that vertex "
                     "itself, with contracted multiply-adds and reciprocal division).  The north star's bar is "
-                    "1e-8 on sd^2; tools/gpu_tolerance_report.py checks every fixture (profiles/r04_tolerance_report.json)"}
+                    "1e-8 on sd^2; tools/gpu_tolerance_report.py checks every fixture (profiles/r05_tolerance_report.json)"}
 
 
 def baseline_configs(torch, tb, dev):
