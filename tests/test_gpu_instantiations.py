@@ -1,0 +1,62 @@
+"""EVERY instantiation of the certified lane kernels (kernel family 3) is executed at least once against another kernel family.
+
+Why: these kernels sit at the edge of the register file, and twice a value-identical change of unrelated
+code made ONE instantiation return wrong results on every input (round 3: feasible sets at 11 / 13 dof; round 5: the forward
+profiles of <5 dof, TOPPRAsd>) while its neighbours stayed right.  Such a defect is input-independent, so a small random batch
+through each (dof, sd output, grid in LDS or per trajectory, Interpolation or Collocation) instantiation of cert_solve_kernel,
+cert_feasible_kernel and the TOPPRAsd launch -- compared bit for bit with the rows-across-lanes kernels, which share no device code
+with them beyond the row generation -- is a cheap net under all of them (13 dofs x 8 + 13 x 4 + 13 x 4 launches of 96 trajectories)."""
+import numpy as np
+import pytest
+
+from toppra_amd import batch
+
+pytestmark = pytest.mark.gpu
+B, N = 96, 48  # one full 64-lane block and a partial one
+
+
+def _problem(d, seed, per_traj_grid):
+    data = batch.make_synthetic_batch(B, d, N, seed=seed)
+    rng = np.random.default_rng(seed)
+    grid = data["grid"]
+    if per_traj_grid:  # TPR_GRID_PER_TRAJ: the grid is read from global memory instead of the block's LDS copy
+        inner = np.sort(rng.random((B, N - 1)), axis=1) * 0.8 + 0.1
+        grid = 0.5 * np.concatenate([np.zeros((B, 1)), inner, np.ones((B, 1))], axis=1) + 0.5 * np.linspace(0, 1, N + 1)[None, :]
+    sd0 = np.where(rng.random(B) < 0.3, np.round(0.1 * rng.random(B) * 1024) / 1024, 0.0)
+    sd1 = np.where(rng.random(B) < 0.3, np.round(0.2 * rng.random(B) * 1024) / 1024, 0.0)
+    return data, grid, sd0, sd1
+
+
+@pytest.mark.parametrize("d", range(1, 14))
+def test_every_solve_instantiation(gpu, d):
+    for per_traj_grid in (False, True):
+        data, grid, sd0, sd1 = _problem(d, 700 + d, per_traj_grid)
+        for interp in (True, False):
+            for want_sd in (False, True):
+                args = (data["coef"], data["breaks"], grid, data["vlim"], data["alim"], sd0, sd1, interp)
+                want = batch.solve_batch(*args, want_sd=want_sd, variant=2)
+                got = batch.solve_batch(*args, want_sd=want_sd, variant=3)
+                what = (d, per_traj_grid, interp, want_sd)
+                assert np.array_equal(got["status"], want["status"]), what
+                for k in ("K", "sd2", "u") + (("sd",) if want_sd else ()):
+                    assert np.array_equal(got[k], want[k], equal_nan=True), what + (k,)
+                assert (want["status"] == 0).mean() > 0.5, what
+
+
+@pytest.mark.parametrize("d", range(1, 14))
+def test_every_feasible_sets_and_toppra_sd_instantiation(gpu, d):
+    for per_traj_grid in (False, True):
+        data, grid, sd0, sd1 = _problem(d, 800 + d, per_traj_grid)
+        desired = np.random.default_rng(d).uniform(0.5, 5.0, size=B)
+        for interp in (True, False):
+            what = (d, per_traj_grid, interp)
+            X2 = batch.feasible_sets_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], interp, variant=2)
+            X3 = batch.feasible_sets_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], interp, variant=3)
+            assert np.array_equal(X3, X2, equal_nan=True), what + ("X",)
+            a = batch.solve_desired_duration_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], desired, sd0, sd1,
+                                                   variant=2, interpolation=interp)
+            b = batch.solve_desired_duration_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], desired, sd0, sd1,
+                                                   variant=3, interpolation=interp)
+            assert np.array_equal(a["status"], b["status"]), what
+            for k in ("K", "sd2", "sd", "u", "alpha"):
+                assert np.array_equal(a[k], b[k], equal_nan=True), what + (k,)
