@@ -158,7 +158,7 @@ def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
 
 
 @pytest.mark.parametrize("d", [9, 10, 11, 12, 13])
-def test_certified_lane_kernel_above_8_dof(gpu, d):
+def test_certified_lane_kernel_above_8_dof(gpu, oracle, d):
     """Family 3 serves 9..13 dof too (slim blocks, internal row numbering with a block stride of 16, three mask words for the
     80 row numbers), with the same trace-following certificates as below -- there is no other mode: solve (scaled paths,
     boundary velocities, Collocation), feasible sets and TOPPRAsd against the rows-across-lanes kernels -- the full iteration
@@ -176,6 +176,13 @@ def test_certified_lane_kernel_above_8_dof(gpu, d):
             got = batch.solve_batch(*args, **kw)
             for k in ("K", "sd2", "u", "status"):
                 assert np.array_equal(got[k], full[k], equal_nan=True), (k, interp, kw)
+        # ... and the truth is not only another GPU kernel: the first 96 trajectories against the CPU restatement of the reference
+        m = 96
+        flags = oracle.FLAG_VEL | oracle.FLAG_ACC | (oracle.FLAG_INTERP if interp else 0)
+        ref = oracle.solve_batch(args[0][:m], args[1], args[2], args[3][:m], args[4][:m], sd0[:m], sd1[:m], flags=flags, nthreads=0)
+        assert np.array_equal(ref["status"], full["status"][:m]), interp
+        for k in ("K", "sd2", "u"):
+            assert np.array_equal(ref[k], full[k][:m], equal_nan=True), (k, interp)
         fargs = args[:5] + (interp,)
         assert np.array_equal(batch.feasible_sets_batch(*fargs, variant=3), batch.feasible_sets_batch(*fargs, variant=2, strict=True), equal_nan=True)
         desired = rng.uniform(0.3, 6.0, size=B)
@@ -186,7 +193,7 @@ def test_certified_lane_kernel_above_8_dof(gpu, d):
 
 
 @pytest.mark.parametrize("B,d,N", [(1, 9, 7), (65, 13, 5), (3, 12, 2), (130, 10, 1)])
-def test_slim_blocks_partial_and_tiny(gpu, B, d, N):
+def test_slim_blocks_partial_and_tiny(gpu, oracle, B, d, N):
     """The slim blocks of family 3 above 8 dof read the acceleration limits (their own in a row fetch, another lane's in the
     cooperative batches) from global memory and flush K two stages at a time: partial blocks (idle lanes shadow the last
     trajectory), odd and tiny stage counts."""
@@ -200,6 +207,11 @@ def test_slim_blocks_partial_and_tiny(gpu, B, d, N):
         got = batch.solve_batch(*args, variant=3)
         for k in ("K", "sd2", "u", "status"):
             assert np.array_equal(got[k], full[k], equal_nan=True), (k, interp)
+        flags = oracle.FLAG_VEL | oracle.FLAG_ACC | (oracle.FLAG_INTERP if interp else 0)
+        ref = oracle.solve_batch(args[0], args[1], args[2], args[3], args[4], None, sd1, flags=flags, nthreads=0)  # (the CPU restatement)
+        assert np.array_equal(ref["status"], got["status"]), interp
+        for k in ("K", "sd2", "u"):
+            assert np.array_equal(ref[k], got[k], equal_nan=True), (k, interp)
         fargs = args[:5] + (interp,)
         assert np.array_equal(batch.feasible_sets_batch(*fargs, variant=3), batch.feasible_sets_batch(*fargs, variant=2, strict=True), equal_nan=True)
         K = batch.controllable_sets_batch(*args[:5], 0.0, sd1, interp, variant=3)
