@@ -76,3 +76,18 @@ def path_from_tables(coef, breaks):
     path.cspld = pp.derivative()
     path.cspldd = path.cspld.derivative()
     return path
+
+
+def need_reference_solver():
+    """The reference's compiled solver (oracle/_ref) or a SKIP -- but a FAILURE where it is expected: TOPPRA_EXPECT_REF=1
+    (tools/gpu_full.sh, any push from the build container) or the marker oracle/_ref/EXPECTED, which __graft_entry__.build()
+    writes after building the modules and which travels with them.  A snapshot that lost the binaries must not turn the
+    reference-solver tests into silent skips."""
+    import pytest
+    from oracle import build_ref, ref_solver_baseline as rb
+    if rb.available():
+        return rb
+    msg = "oracle/_ref holds no compiled reference solver (built where /root/reference exists)"
+    if os.environ.get("TOPPRA_EXPECT_REF") == "1" or os.path.exists(os.path.join(build_ref.OUT, "EXPECTED")):
+        pytest.fail(msg + " -- and it is expected here (TOPPRA_EXPECT_REF / oracle/_ref/EXPECTED)")
+    pytest.skip(msg)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from toppra_amd import batch
+from tests.helpers import need_reference_solver
 
 pytestmark = pytest.mark.gpu
 
@@ -358,9 +359,7 @@ def test_sliver_family_against_the_references_own_compiled_solver(gpu, B, d, N, 
     has an optimum (cy_seidel_solverwrapper.pyx:127,:342,:353-355) -- against the reference ITSELF: its compiled
     cy_seidel_solverwrapper (oracle/_ref) under the reference's two passes (oracle/ref_solver_baseline.py), every kernel
     family and the default choice, K, sd, u and the failures bit for bit (a cut of tools/gpu_vs_reference_solver.py)."""
-    from oracle import ref_solver_baseline as rb
-    if not rb.available():
-        pytest.skip("oracle/_ref holds no compiled reference solver (built where /root/reference exists)")
+    rb = need_reference_solver()
     (coef, breaks, grid, vlim, alim, sd0, sd1), _ = _tool("gpu_sliver_hunt").family(B, d, N, seed)
     sd1 = np.round(np.asarray(sd1) * 1024) / 1024  # exact squares: ** in the reference's passes, sd * sd on the device
     ref = []

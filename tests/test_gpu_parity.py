@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from toppra_amd import batch
+from tests.helpers import need_reference_solver
 
 pytestmark = pytest.mark.gpu
 
@@ -248,9 +249,7 @@ def test_against_the_references_own_compiled_solver(gpu, d, N, seed):
     """Not the restatement: the reference's compiled cy_seidel_solverwrapper (oracle/_ref, built from the sources under
     /root/reference and shipped as a binary) driven by the reference's two passes (oracle/ref_solver_baseline.py), against
     every kernel family -- K, sd, u bit for bit, failures included; scaled paths and non-zero boundary velocities."""
-    from oracle import ref_solver_baseline as rb
-    if not rb.available():
-        pytest.skip("oracle/_ref holds no compiled reference solver (built where /root/reference exists)")
+    rb = need_reference_solver()
     B = 24
     data = batch.make_synthetic_batch(B, d, N, seed=seed)
     rng = np.random.default_rng(seed)
@@ -282,9 +281,7 @@ def test_against_the_references_own_compiled_solver(gpu, d, N, seed):
 def test_sets_against_the_references_own_compiled_solver(gpu, d, N, seed):
     """compute_feasible_sets and compute_controllable_sets(sdmin, sdmax) of the reference's compiled solver under the
     reference's loops (oracle/ref_solver_baseline.py) against the HIP entries, every family, bit for bit."""
-    from oracle import ref_solver_baseline as rb
-    if not rb.available():
-        pytest.skip("oracle/_ref holds no compiled reference solver (built where /root/reference exists)")
+    rb = need_reference_solver()
     B = 16
     data = batch.make_synthetic_batch(B, d, N, seed=seed)
     rng = np.random.default_rng(seed)

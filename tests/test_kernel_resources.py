@@ -76,3 +76,30 @@ def test_headline_instantiations_keep_their_shape(resources, d, gl):
     n0, b0 = CEILINGS[(d, gl)]
     assert 0.5 * n0 < insts <= 1.05 * n0, (d, gl, "instructions", insts, n0)
     assert branches <= 1.10 * b0 + 1, (d, gl, "s_cbranch_exec*", branches, b0)
+
+
+# ---- the register allocator's copy above an exec restore (profiles/r06_miscompile_root_cause.md) -------------------------------
+# The cause of round 3's and round 5's wrong results: LLVM's VGPR allocation phase can place a live-range-split copy above a join
+# block's `s_or_b64 exec, exec, ...`, where it runs under the closed region's mask.  toppra_amd.build checks every unit of kernel
+# family 3 for it on MIR (exact); here the built library's own code objects are disassembled and scanned, every kernel of every
+# family, and the detector itself is pinned on the committed single-kernel reproducer.
+
+def test_no_vector_instruction_above_an_exec_restore():
+    import exec_restore_scan as ers
+    from toppra_amd import build
+    build.build()
+    hits = ers.scan_lib(os.path.join(ROOT, "toppra_amd", "libtoppra_hip.so"))
+    assert not hits, [(h[0], h[1], h[2][:2]) for h in hits]
+
+
+def test_the_detector_flags_the_round_5_reproducer(tmp_path):
+    import lzma
+    from toppra_amd import codegen_check
+    ir = tmp_path / "k.ll"
+    ir.write_bytes(lzma.open(os.path.join(ROOT, "tools", "r6", "repro", "sd5_sdfwd_signbits_kernel.ll.xz")).read())
+    mir = tmp_path / "k.mir"
+    subprocess.run(["/opt/rocm/lib/llvm/bin/llc", "-O3", "-mtriple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-stop-after=virtregrewriter,2",
+                    str(ir), "-o", str(mir)], check=True, capture_output=True)
+    hits = codegen_check.scan_mir(str(mir))
+    assert len(hits) == 2, hits
+    assert any("$agpr0_agpr1 = COPY killed renamable $vgpr228_vgpr229" in h[2][0] for h in hits), hits

@@ -7,6 +7,7 @@
 # judged into profiles/ (tools/collect_profiles.sh).
 set -u
 mkdir -p gpurun_out; export TMPDIR=/tmp
+export TOPPRA_EXPECT_REF=1   # the reference-solver tests FAIL (not skip) if oracle/_ref did not travel
 timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -5 | tee gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/smoke.log
 timeout 600 python tools/gpu_measure.py 2>/dev/null > gpurun_out/measure.json; tail -5 gpurun_out/measure.json

@@ -70,7 +70,11 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
         jobs = [(main, os.path.join(tmp, "main.o"), ["-DTPR_CERT_MAX_DOF=%d" % max_dof])]
         for d in range(1, max_dof + 1):
             extra = os.environ.get("TPR_BUILD_CERT_FLAGS_ABOVE_8", "").split() if d > 8 else []  # (compiler experiments)
-            extra += os.environ.get("TPR_BUILD_CERT_FLAGS", "").split()
+            # TPR_BUILD_CERT_FLAGS: experiment flags for family 3's translation units -- with TPR_BUILD_ONLY_CERT_DOFS, for the
+            # selected dofs ONLY (the other dofs keep the product's flags, hence the product's cached objects)
+            only_dofs = os.environ.get("TPR_BUILD_ONLY_CERT_DOFS", "").split()
+            if not only_dofs or str(d) in only_dofs:
+                extra += os.environ.get("TPR_BUILD_CERT_FLAGS", "").split()
             jobs.append((os.path.join(CSRC, "tpr_cert_tu.hip"), os.path.join(tmp, "cert%d.o" % d), ["-DTPR_TU_D=%d" % d] + extra))
         for half in (0, 1):  # the robust (conic) kernels: 1..8 dof + the lane kernel, 9..16 dof
             jobs.append((os.path.join(CSRC, "tpr_robust_tu.hip"), os.path.join(tmp, "robust%d.o" % half), ["-DTPR_TU_HALF=%d" % half]))
@@ -98,6 +102,8 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
         except OSError:
             cc_id = cc
         only = os.environ.get("TPR_BUILD_ONLY_CERT_DOFS", "").split()
+        # (an object in the cache has passed the check: objects are only cached after it)
+        verify = os.environ.get("TPR_BUILD_VERIFY", "1") != "0" and not defines
 
         def run(job):
             src, obj, extra = job
@@ -107,29 +113,63 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
             cached = os.path.join(cache, "%s_%s_%s.o" % (name, fkey, skey))
             stale_ok = only and name.startswith("cert") and name[4:] not in only
             if stale_ok and not os.path.exists(cached):
-                olds = sorted((f for f in os.listdir(cache) if f.startswith("%s_%s_" % (name, fkey))), key=lambda f: os.path.getmtime(os.path.join(cache, f)))
+                olds = sorted((f for f in os.listdir(cache) if f.startswith("%s_%s_" % (name, fkey)) and f.endswith(".o")),
+                              key=lambda f: os.path.getmtime(os.path.join(cache, f)))
                 if olds:
                     cached = os.path.join(cache, olds[-1])
-            if os.path.exists(cached):
-                shutil.copyfile(cached, obj)
-                return obj
+            try:  # (another builder may evict the object between the test and the copy: recompile then)
+                if os.path.exists(cached):
+                    shutil.copyfile(cached, obj)
+                    return obj
+            except OSError:
+                pass
             cmd = [cc] + cflags + dflags + extra + ["-c", "-o", obj, src]
             if verbose:
                 print(" ".join(cmd))
+            checker = None
+            if verify and name.startswith("cert"):
+                # Code-generation check (codegen_check.py): the same compile stopped after the last register-allocation phase,
+                # scanned for vector copies above an exec restore -- in parallel with the real compile.  A unit that shows the
+                # pattern is not linked: its results would depend on which lanes a divergent region happened to cover.
+                from concurrent.futures import ThreadPoolExecutor as _TPE
+                from . import codegen_check
+
+                def check():
+                    mir = obj[:-2] + ".mir"
+                    subprocess.check_call([cc] + cflags + dflags + extra + ["--cuda-device-only", "-S", "-mllvm", "-stop-after=virtregrewriter,2",
+                                                                            "-o", mir, src], cwd=CSRC, stderr=subprocess.DEVNULL)
+                    return codegen_check.scan_mir(mir)
+                checker = _TPE(max_workers=1)
+                pending = checker.submit(check)
             subprocess.check_call(cmd, cwd=CSRC)
-            for f in os.listdir(cache):  # one object per unit and flag set
-                if f.startswith("%s_%s_" % (name, fkey)):
+            if checker is not None:
+                hits = pending.result()
+                checker.shutdown()
+                if hits:
+                    raise RuntimeError("code-generation check failed for %s %s: vector instructions above an exec restore in\n  %s\n"
+                                       "(profiles/r06_miscompile_root_cause.md; change the unit's spelling -- e.g. TPR_SIGNBITS_*_DOFS -- "
+                                       "or set TPR_BUILD_VERIFY=0 for an experiment)" %
+                                       (os.path.basename(src), " ".join(extra), "\n  ".join("%s %s: %s" % (h[0], h[1], h[2][0][:100]) for h in hits)))
+            final = os.path.join(cache, "%s_%s_%s.o" % (name, fkey, skey))
+            for f in os.listdir(cache):  # one object per unit and flag set: finished objects only, never another builder's *.tmp
+                if f.startswith("%s_%s_" % (name, fkey)) and f.endswith(".o") and f != os.path.basename(final):
                     try:
                         os.remove(os.path.join(cache, f))
                     except OSError:
                         pass
-            tmp_obj = "%s.%d.tmp" % (cached, os.getpid())
-            shutil.copyfile(obj, tmp_obj)
-            os.replace(tmp_obj, cached)
+            try:
+                tmp_obj = "%s.%d.tmp" % (final, os.getpid())
+                shutil.copyfile(obj, tmp_obj)
+                os.replace(tmp_obj, final)
+            except OSError:
+                pass  # (the cache is an optimisation; the object in `obj` is what gets linked)
             return obj
 
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             objs = list(pool.map(run, jobs))
+        if os.environ.get("TPR_BUILD_KEEP_OBJS"):  # (tools/r6/build_cert_variants.py: the objects, for linking variants elsewhere)
+            for o in objs:
+                shutil.copyfile(o, os.path.join(os.environ["TPR_BUILD_KEEP_OBJS"], os.path.basename(o)))
         cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
         if verbose:
             print(" ".join(cmd))

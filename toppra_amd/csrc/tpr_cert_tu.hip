@@ -28,6 +28,15 @@ constexpr bool kSoundKernels = false;
 constexpr bool kSoundKernels = true;
 #endif
 
+// The grid-in-LDS instantiations exist up to 8 dof only (above, the grid is read from global memory: see the launchers): a
+// kernel that is never launched is not compiled either -- half the compile time of the 9..13-dof units, and nothing unlaunched
+// for the build's code-generation check (toppra_amd/codegen_check.py) to trip over.
+#define TPR_IF_GRID_LDS(T, F)                                   \
+    do {                                                        \
+        if constexpr (D <= 8) { if (grid_lds) { T; } else { F; } } \
+        else { F; }                                             \
+    } while (0)
+
 #define TPR_TU_CAT2(a, b) a##b
 #define TPR_TU_CAT(a, b) TPR_TU_CAT2(a, b)
 
@@ -45,10 +54,10 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_laun
                                tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + CS::kRing * 2 * BS) * sizeof(double);
     // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
     // wave per SIMD --, three at 9..11 dof, two above)
-    // ... and only up to 8 dof: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
-    // were off in the last bits on 0.9 % of an irregular batch (tools/gpu_r3_stress.py) while the same source with the grid
-    // read from global memory, with fast certificates, or with one more debug store is bit-exact -- not understood
-    // (DESIGN.md section 4.1); above 8 dof the grid is read from global memory.
+    // ... and only up to 8 dof (round 3: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
+    // were off in the last bits on 0.9 % of an irregular batch while value-identical spellings were bit-exact -- the signature of
+    // the register allocator's copy above the exec restore, profiles/r06_miscompile_root_cause.md, which the build now checks
+    // for); above 8 dof the grid is read from global memory, and those instantiations are not compiled (TPR_IF_GRID_LDS).
     const bool grid_lds = D <= 8 && !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
     // One 64-lane block per wave; ~39 KB of LDS per block leaves one wave per SIMD, which the kernel
@@ -56,11 +65,11 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_laun
 #define TPR_LAUNCH_CERT(SD, GL, IN, SO) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, SD, GL, IN, SO>), grid, block, lds, stream, G)
 #define TPR_LAUNCH_CERT3(SD, GL, IN) TPR_LAUNCH_CERT(SD, GL, IN, kSoundKernels)
     if (G.flags & TPR_ACC_INTERPOLATION) {
-        if (G.sd) { if (grid_lds) TPR_LAUNCH_CERT3(true, true, true); else TPR_LAUNCH_CERT3(true, false, true); }
-        else { if (grid_lds) TPR_LAUNCH_CERT3(false, true, true); else TPR_LAUNCH_CERT3(false, false, true); }
+        if (G.sd) TPR_IF_GRID_LDS(TPR_LAUNCH_CERT3(true, true, true), TPR_LAUNCH_CERT3(true, false, true));
+        else TPR_IF_GRID_LDS(TPR_LAUNCH_CERT3(false, true, true), TPR_LAUNCH_CERT3(false, false, true));
     } else {  // Collocation
-        if (G.sd) { if (grid_lds) TPR_LAUNCH_CERT3(true, true, false); else TPR_LAUNCH_CERT3(true, false, false); }
-        else { if (grid_lds) TPR_LAUNCH_CERT3(false, true, false); else TPR_LAUNCH_CERT3(false, false, false); }
+        if (G.sd) TPR_IF_GRID_LDS(TPR_LAUNCH_CERT3(true, true, false), TPR_LAUNCH_CERT3(true, false, false));
+        else TPR_IF_GRID_LDS(TPR_LAUNCH_CERT3(false, true, false), TPR_LAUNCH_CERT3(false, false, false));
     }
 #undef TPR_LAUNCH_CERT3
 #undef TPR_LAUNCH_CERT
@@ -78,17 +87,17 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feas
                                tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + CS::kRing * 2 * BS) * sizeof(double);
     // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
     // wave per SIMD --, three at 9..11 dof, two above)
-    // ... and only up to 8 dof: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
-    // were off in the last bits on 0.9 % of an irregular batch (tools/gpu_r3_stress.py) while the same source with the grid
-    // read from global memory, with fast certificates, or with one more debug store is bit-exact -- not understood
-    // (DESIGN.md section 4.1); above 8 dof the grid is read from global memory.
+    // ... and only up to 8 dof (round 3: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
+    // were off in the last bits on 0.9 % of an irregular batch while value-identical spellings were bit-exact -- the signature of
+    // the register allocator's copy above the exec restore, profiles/r06_miscompile_root_cause.md, which the build now checks
+    // for); above 8 dof the grid is read from global memory, and those instantiations are not compiled (TPR_IF_GRID_LDS).
     const bool grid_lds = D <= 8 && !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
     const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;
 #define TPR_LAUNCH_FEAS(GL, IN, SO) hipLaunchKernelGGL((tpr::cert_feasible_kernel<D, BS, GL, IN, SO>), grid, block, lds, stream, G, X)
 #define TPR_LAUNCH_FEAS2(GL, IN) TPR_LAUNCH_FEAS(GL, IN, kSoundKernels)
-    if (interp) { if (grid_lds) TPR_LAUNCH_FEAS2(true, true); else TPR_LAUNCH_FEAS2(false, true); }
-    else { if (grid_lds) TPR_LAUNCH_FEAS2(true, false); else TPR_LAUNCH_FEAS2(false, false); }
+    if (interp) TPR_IF_GRID_LDS(TPR_LAUNCH_FEAS2(true, true), TPR_LAUNCH_FEAS2(false, true));
+    else TPR_IF_GRID_LDS(TPR_LAUNCH_FEAS2(true, false), TPR_LAUNCH_FEAS2(false, false));
 #undef TPR_LAUNCH_FEAS2
 #undef TPR_LAUNCH_FEAS
     return 0;
@@ -105,17 +114,17 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_l
     const size_t static_lds = (cols + tpr::kCertXch * BS + tpr::cert_batch_groups<D>() * tpr::GroupCfg<D, tpr::kCertBatchLanes>::kRowBuf + CS::kRing * 2 * BS) * sizeof(double);
     // the shared grid goes to LDS only while that does not cost a block per CU (160 KB: four blocks up to 8 dof -- one
     // wave per SIMD --, three at 9..11 dof, two above)
-    // ... and only up to 8 dof: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
-    // were off in the last bits on 0.9 % of an irregular batch (tools/gpu_r3_stress.py) while the same source with the grid
-    // read from global memory, with fast certificates, or with one more debug store is bit-exact -- not understood
-    // (DESIGN.md section 4.1); above 8 dof the grid is read from global memory.
+    // ... and only up to 8 dof (round 3: the <9 dof, grid in LDS, sound certificates> instantiation returned lower bounds that
+    // were off in the last bits on 0.9 % of an irregular batch while value-identical spellings were bit-exact -- the signature of
+    // the register allocator's copy above the exec restore, profiles/r06_miscompile_root_cause.md, which the build now checks
+    // for); above 8 dof the grid is read from global memory, and those instantiations are not compiled (TPR_IF_GRID_LDS).
     const bool grid_lds = D <= 8 && !(G.flags & TPR_GRID_PER_TRAJ) && (160 * 1024) / (static_lds + grid_bytes) == (160 * 1024) / static_lds;
     const size_t lds = grid_lds ? grid_bytes : 0;
     const bool interp = (G.flags & TPR_ACC_INTERPOLATION) != 0;
 #define TPR_LAUNCH_SD(GL, IN, SO) hipLaunchKernelGGL((tpr::cert_solve_kernel<D, BS, false, GL, IN, SO, true>), grid, block, lds, stream, G)
 #define TPR_LAUNCH_SD2(GL, IN) TPR_LAUNCH_SD(GL, IN, kSoundKernels)
-    if (interp) { if (grid_lds) TPR_LAUNCH_SD2(true, true); else TPR_LAUNCH_SD2(false, true); }
-    else { if (grid_lds) TPR_LAUNCH_SD2(true, false); else TPR_LAUNCH_SD2(false, false); }
+    if (interp) TPR_IF_GRID_LDS(TPR_LAUNCH_SD2(true, true), TPR_LAUNCH_SD2(false, true));
+    else TPR_IF_GRID_LDS(TPR_LAUNCH_SD2(true, false), TPR_LAUNCH_SD2(false, false));
 #undef TPR_LAUNCH_SD2
 #undef TPR_LAUNCH_SD
     return 0;
