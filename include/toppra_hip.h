@@ -85,7 +85,9 @@ typedef struct tpr_problem {
     int32_t variant; /* kernel selection: 0 = auto, 1 = generic lane-per-trajectory, 2 = rows-across-lanes,
                         3 = lane-per-trajectory certificates (d <= 13; sd2, u, status required),
                         4 = one trajectory per wave (the latency kernel: any dof, N <= 1480; auto for
-                            small batches) */
+                            small batches),
+                        5 = two trajectories per wave, 32 lanes each (the fused solve for 1..7 dof, N <= ~800;
+                            auto between 1536 and 9215 trajectories) */
     const double *coef;
     const double *breaks;
     const double *grid;

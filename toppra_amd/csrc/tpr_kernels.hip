@@ -16,6 +16,7 @@
 #include "tpr_lane.hip.inc"
 #include "tpr_group.hip.inc"
 #include "tpr_wave.hip.inc"
+#include "tpr_pair.hip.inc"
 #include "tpr_spline.hip.inc"
 #include "tpr_param.hip.inc"
 #include "tpr_robust_args.hpp"
@@ -240,6 +241,12 @@ tpr::BatchArgs stage_problem(const tpr_problem *p, Staging &S) {
 }
 
 constexpr size_t kMaxDynamicLds = 64 * 1024;
+#ifndef TPR_PAIR_AUTO_MIN_BATCH
+#define TPR_PAIR_AUTO_MIN_BATCH 2560   // auto: two trajectories per wave between these batch sizes (tools/gpu_crossover.py)
+#endif
+#ifndef TPR_PAIR_AUTO_MAX_BATCH
+#define TPR_PAIR_AUTO_MAX_BATCH 9215
+#endif
 #ifndef TPR_WAVE_AUTO_MAX_BATCH
 #define TPR_WAVE_AUTO_MAX_BATCH 5120  // auto: one wave per trajectory up to this many trajectories (4096: 0.86 vs 1.11 ms for
                                       // family 2; 8192: 1.51 vs 1.31 -- tools/gpu_wave_check.py)
@@ -553,6 +560,24 @@ int launch_wave(const tpr::BatchArgs &A, hipStream_t stream) {
     return TPR_E_OK;
 }
 
+// Family 5 (two trajectories per wave, 32 lanes each): the fused solve for 1..7 dof; both trajectories' LDS tables in one
+// block.  Not the wrapper's warm-start state, not the stand-alone backward scan, not feasible sets (family 4 has those).
+size_t pair_lds_bytes(const tpr::BatchArgs &A, bool table_in_lds) {
+    return 2 * ((tpr::wave_lds_doubles(A.N, A.nseg, A.d, table_in_lds) + 1) & ~(size_t)1) * sizeof(double);
+}
+bool pair_supported(const tpr::BatchArgs &A) {
+    return A.d >= 1 && A.d <= 7 && A.N >= 1 && A.nseg <= 65535 && !A.active && !A.feasible_X && !A.backward_only && !A.sd_end_hi &&
+           pair_lds_bytes(A, false) <= kMaxDynamicLds;
+}
+int launch_pair(const tpr::BatchArgs &A, hipStream_t stream) {
+    const bool table = pair_lds_bytes(A, true) <= kMaxDynamicLds;
+    const size_t lds = pair_lds_bytes(A, table);
+    const dim3 grid((A.B + 1) / 2), block(64);
+    if (table) hipLaunchKernelGGL((tpr::pair_solve_kernel<true>), grid, block, lds, stream, A);
+    else hipLaunchKernelGGL((tpr::pair_solve_kernel<false>), grid, block, lds, stream, A);
+    return TPR_E_OK;
+}
+
 // Batch size from which family 3 is the automatic choice (solve, TOPPRAsd).
 int cert_auto_from(int d) { return d <= 8 ? 9216 : (d <= 10 ? 18432 : 22528); }
 
@@ -566,6 +591,10 @@ int pick_variant(int requested, const tpr::BatchArgs &A) {
     // wave per trajectory (family 4).  Family 3 finishes up to 65536 trajectories (one wave per SIMD) in one
     // fixed-latency round, which beats family 2's throughput from about a quarter of that batch upward
     // (tools/gpu_crossover.py); family 2 serves the strict mode and what is left.
+    // ... two trajectories per wave (family 5) from the batch size at which one wave per trajectory stops being free: the
+    // chip holds 1024 waves at one per SIMD, and family 4's waves leave half their lanes idle at <= 7 dof
+    // (... while eight blocks still fit a CU's LDS -- two waves per SIMD, all a 4096-trajectory batch can use: N <= ~240 at 7 dof)
+    if (pair_supported(A) && A.B >= TPR_PAIR_AUTO_MIN_BATCH && A.B <= TPR_PAIR_AUTO_MAX_BATCH && pair_lds_bytes(A, true) <= 160 * 1024 / 8) return 5;
     if (wave_supported(A) && A.B <= TPR_WAVE_AUTO_MAX_BATCH) return 4;
     // (round 4, after families 2 and 4 learnt to follow the lower-bound trace too: at 7 dof family 2 leads between ~5600 and
     // ~9200 trajectories, 1.7 - 1.9 ms against family 3's 2.1 - 2.2 at any size up to 65536; the slim blocks of 9..13 dof
@@ -580,6 +609,11 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
     if (A.active && (variant == 2 || variant == 3))
         return fail(TPR_E_UNSUPPORTED, "tpr_problem.active (warm-start state in / out) is maintained by kernel families 4 and 1 only: leave variant at 0");
     switch (variant) {
+        case 5: {
+            if (!pair_supported(A))
+                return fail(TPR_E_UNSUPPORTED, "variant 5 (two trajectories per wave) serves the fused solve for 1..7 dof with N <= ~800 and no warm-start state");
+            return launch_pair(A, stream);
+        }
         case 4: {
             if (!wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables (N <= 1480)");
             return launch_wave(A, stream);
