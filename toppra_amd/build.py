@@ -49,6 +49,16 @@ CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "13"))
 CERT_DOFS = tuple(range(1, CERT_MAX_DOF + 1))
 
 
+# Per-dof compiler flags of kernel family 3's units, chosen by TIMING among the code generations that pass the check of
+# codegen_check.py (65536 x d x 200, profiles/r06_dofs_matrix.log): above 8 dof the kernels fill the register file, and what the
+# allocator makes of them moves by tens of percent with flags that change nothing else.
+CERT_UNIT_FLAGS = {9: ["-fno-slp-vectorize"], 10: ["-fno-slp-vectorize"], 13: ["-mllvm", "-greedy-reverse-local-assignment=1"]}
+# ... and what the build tries next, in this order, when a unit's code shows a vector copy above an exec restore
+# (profiles/r06_miscompile_root_cause.md): the first clean code generation is linked, none is an error.
+CERT_FLAG_LADDER = [[], ["-fno-slp-vectorize"], ["-mllvm", "-greedy-reverse-local-assignment=1"],
+                    ["-fno-slp-vectorize", "-mllvm", "-greedy-reverse-local-assignment=1"]]
+
+
 def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=None):
     """hipcc the translation units in parallel (the certified lane kernels are most of the compile time: one unit per
     dof), then link the objects into `target`.  Instrumented development builds (`defines`) are ONE translation unit:
@@ -75,6 +85,8 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
             only_dofs = os.environ.get("TPR_BUILD_ONLY_CERT_DOFS", "").split()
             if not only_dofs or str(d) in only_dofs:
                 extra += os.environ.get("TPR_BUILD_CERT_FLAGS", "").split()
+            if not extra and not defines:  # (no experiment on this dof: the product's flags for it)
+                extra = list(CERT_UNIT_FLAGS.get(d, []))
             jobs.append((os.path.join(CSRC, "tpr_cert_tu.hip"), os.path.join(tmp, "cert%d.o" % d), ["-DTPR_TU_D=%d" % d] + extra))
         for half in (0, 1):  # the robust (conic) kernels: 1..8 dof + the lane kernel, 9..16 dof
             jobs.append((os.path.join(CSRC, "tpr_robust_tu.hip"), os.path.join(tmp, "robust%d.o" % half), ["-DTPR_TU_HALF=%d" % half]))
@@ -123,33 +135,43 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
                     return obj
             except OSError:
                 pass
-            cmd = [cc] + cflags + dflags + extra + ["-c", "-o", obj, src]
-            if verbose:
-                print(" ".join(cmd))
-            checker = None
+            # Family 3's units go through the code-generation check (codegen_check.py): the same compile stopped after the last
+            # register-allocation phase, scanned for vector copies above an exec restore, in parallel with the real compile.  A
+            # unit that shows the pattern is compiled again with the next flags of CERT_FLAG_LADDER; no clean rung: no library.
+            rungs = [[]]
             if verify and name.startswith("cert"):
-                # Code-generation check (codegen_check.py): the same compile stopped after the last register-allocation phase,
-                # scanned for vector copies above an exec restore -- in parallel with the real compile.  A unit that shows the
-                # pattern is not linked: its results would depend on which lanes a divergent region happened to cover.
-                from concurrent.futures import ThreadPoolExecutor as _TPE
-                from . import codegen_check
+                rungs = [[]] + [r for r in CERT_FLAG_LADDER if r and not all(f in extra for f in r)]
+            problems = []
+            for rung in rungs:
+                cmd = [cc] + cflags + dflags + extra + rung + ["-c", "-o", obj, src]
+                if verbose:
+                    print(" ".join(cmd))
+                checker = None
+                if verify and name.startswith("cert"):
+                    from concurrent.futures import ThreadPoolExecutor as _TPE
+                    from . import codegen_check
 
-                def check():
-                    mir = obj[:-2] + ".mir"
-                    subprocess.check_call([cc] + cflags + dflags + extra + ["--cuda-device-only", "-S", "-mllvm", "-stop-after=virtregrewriter,2",
-                                                                            "-o", mir, src], cwd=CSRC, stderr=subprocess.DEVNULL)
-                    return codegen_check.scan_mir(mir)
-                checker = _TPE(max_workers=1)
-                pending = checker.submit(check)
-            subprocess.check_call(cmd, cwd=CSRC)
-            if checker is not None:
-                hits = pending.result()
-                checker.shutdown()
-                if hits:
-                    raise RuntimeError("code-generation check failed for %s %s: vector instructions above an exec restore in\n  %s\n"
-                                       "(profiles/r06_miscompile_root_cause.md; change the unit's spelling -- e.g. TPR_SIGNBITS_*_DOFS -- "
-                                       "or set TPR_BUILD_VERIFY=0 for an experiment)" %
-                                       (os.path.basename(src), " ".join(extra), "\n  ".join("%s %s: %s" % (h[0], h[1], h[2][0][:100]) for h in hits)))
+                    def check(rung=rung):
+                        mir = obj[:-2] + ".mir"
+                        subprocess.check_call([cc] + cflags + dflags + extra + rung + ["--cuda-device-only", "-S", "-mllvm", "-stop-after=virtregrewriter,2",
+                                                                                       "-o", mir, src], cwd=CSRC, stderr=subprocess.DEVNULL)
+                        return codegen_check.scan_mir(mir)
+                    checker = _TPE(max_workers=1)
+                    pending = checker.submit(check)
+                subprocess.check_call(cmd, cwd=CSRC)
+                hits = []
+                if checker is not None:
+                    hits = pending.result()
+                    checker.shutdown()
+                if not hits:
+                    if rung or problems:
+                        print("toppra_amd.build: %s %s: clean with %s after %d flagged code generation(s)" % (name, " ".join(extra), rung or "the unit's flags", len(problems)))
+                    break
+                problems.append("%s: %s" % (" ".join(extra + rung) or "(no extra flags)", "; ".join("%s %s: %s" % (h[0], h[1], h[2][0][:90]) for h in hits)))
+            else:
+                raise RuntimeError("code-generation check failed for %s with every flag set tried: vector instructions above an exec restore\n  %s\n"
+                                   "(profiles/r06_miscompile_root_cause.md; change the unit's spelling -- e.g. TPR_SIGNBITS_*_DOFS -- "
+                                   "or set TPR_BUILD_VERIFY=0 for an experiment)" % (os.path.basename(src), "\n  ".join(problems)))
             final = os.path.join(cache, "%s_%s_%s.o" % (name, fkey, skey))
             for f in os.listdir(cache):  # one object per unit and flag set: finished objects only, never another builder's *.tmp
                 if f.startswith("%s_%s_" % (name, fkey)) and f.endswith(".o") and f != os.path.basename(final):

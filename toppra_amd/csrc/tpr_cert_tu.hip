@@ -37,6 +37,19 @@ constexpr bool kSoundKernels = true;
         else { F; }                                             \
     } while (0)
 
+// Slim blocks (above 8 dof): the per-block transposed workspace of GroupArgs::tws, stream-ordered around the launch.
+struct TwsScope {
+    void *ws = nullptr;
+    hipStream_t stream;
+    hipError_t err = hipSuccess;
+    TwsScope(tpr::GroupArgs &G, int d, int blocks, hipStream_t st) : stream(st) {
+        if (d <= 8) return;
+        err = hipMallocAsync(&ws, (size_t)blocks * tpr::cert_tws_fields(d, G.nseg) * 64 * sizeof(double), st);
+        G.tws = static_cast<double *>(ws);
+    }
+    ~TwsScope() { if (ws) (void)hipFreeAsync(ws, stream); }
+};
+
 #define TPR_TU_CAT2(a, b) a##b
 #define TPR_TU_CAT(a, b) TPR_TU_CAT2(a, b)
 
@@ -44,8 +57,10 @@ constexpr bool kSoundKernels = true;
 // Returns 0, or -1 when the launch geometry cannot be met (never for supported shapes).
 extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, hipStream_t stream) {
     constexpr int D = TPR_TU_D, BS = 64;
-    const tpr::GroupArgs &G = *Gp;
+    tpr::GroupArgs G = *Gp;
     const dim3 grid((G.B + BS - 1) / BS), block(BS);
+    TwsScope tws(G, D, (int)grid.x, stream);
+    if (tws.err != hipSuccess) return -1;
     // the shared grid goes to LDS only while four blocks still fit a CU (160 KB): a fifth of the
     // 1024 blocks of a 65536-trajectory batch would otherwise wait for a second round
     const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
@@ -79,8 +94,10 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_laun
 // compute_feasible_sets on the certified lane design (cert_feasible_kernel): X [B][N+1][2].
 extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feasible_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, double *X, hipStream_t stream) {
     constexpr int D = TPR_TU_D, BS = 64;
-    const tpr::GroupArgs &G = *Gp;
+    tpr::GroupArgs G = *Gp;
     const dim3 grid((G.B + BS - 1) / BS), block(BS);
+    TwsScope tws(G, D, (int)grid.x, stream);
+    if (tws.err != hipSuccess) return -1;
     const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
     using CS = tpr::CertStage<D, BS>;
     const size_t static_lds = (((4 * D + CS::kLimCols) > 24 ? (4 * D + CS::kLimCols) : 24) * BS + tpr::kCertXch * BS +
@@ -106,8 +123,10 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feas
 // TOPPRAsd: backward scan + the fastest / slowest forward profiles in one launch (cert_solve_kernel<..., SDFWD = true>).
 extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, hipStream_t stream) {
     constexpr int D = TPR_TU_D, BS = 64;
-    const tpr::GroupArgs &G = *Gp;
+    tpr::GroupArgs G = *Gp;
     const dim3 grid((G.B + BS - 1) / BS), block(BS);
+    TwsScope tws(G, D, (int)grid.x, stream);
+    if (tws.err != hipSuccess) return -1;
     const size_t grid_bytes = (size_t)(G.N + 1) * sizeof(double);
     using CS = tpr::CertStage<D, BS>;
     const size_t cols = ((4 * D + CS::kLimCols) > 32 ? (4 * D + CS::kLimCols) : 32) * BS;

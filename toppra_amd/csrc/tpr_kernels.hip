@@ -829,7 +829,8 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream_) {
         tpr::BatchArgs probe = A;  // the variant the call will take, with every output it could ask a workspace for
         if (!probe.u) probe.u = reinterpret_cast<double *>(8);
         if (!probe.K) probe.K = reinterpret_cast<double *>(8);
-        if (pick_variant(p->variant, probe) != 4) {
+        const int v = pick_variant(p->variant, probe);
+        if (v != 4 && v != 5) {  // (families 4 and 5 keep K in LDS and skip what is not asked for)
             if (!A.u) A.u = workspace(B * N);
             if (!A.K) A.K = workspace(B * (N + 1) * 2);
         }
