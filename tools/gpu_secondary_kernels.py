@@ -57,6 +57,10 @@ def main():
     d2 = tb.make_synthetic_batch(4096, 7, 200)
     dv2 = dev_args(d2)
     cases["family4_4096x7x200"] = lambda: tb.solve_batch(*dv2, variant=4)
+    cases["family5_4096x7x200"] = lambda: tb.solve_batch(*dv2, variant=5)
+    d1 = tb.make_synthetic_batch(1, 7, 100)
+    dv1 = dev_args(d1)
+    cases["family4_1x7x100"] = lambda: tb.solve_batch(*dv1, variant=4)
     d4 = tb.make_synthetic_batch(16384, 7, 100)
     dv4 = dev_args(d4)
     cases["robust_config4_16384x7x100"] = lambda: tb.robust_solve_batch(*dv4, [1e-3, 5e-2, 9e-3])

@@ -540,16 +540,26 @@ bool wave_supported(const tpr::BatchArgs &A) {
     return A.d >= 1 && A.d <= TPR_MAX_DOF && A.N >= 1 && A.nseg <= 65535 && wave_lds_bytes(A, false) <= kMaxDynamicLds;
 }
 
+#ifndef TPR_WAVE_SPLIT_MAX_BATCH
+#define TPR_WAVE_SPLIT_MAX_BATCH 768  // two waves per trajectory (one per LP of a backward stage) up to this many trajectories
+#endif
 int launch_wave(const tpr::BatchArgs &A, hipStream_t stream) {
     const bool table = wave_lds_bytes(A, true) <= kMaxDynamicLds;
     const size_t lds = wave_lds_bytes(A, table);
     const int slots = (4 * A.d + 6 + 63) / 64;  // virtual rows per LP / 64 lanes
-    const dim3 grid(A.B), block(64);
+    // a handful of trajectories (BASELINE config 1): the two LPs of a backward stage on two waves (wave_solve_kernel<.., SPLIT>)
+    const bool split = slots == 1 && !A.feasible_X && A.B <= TPR_WAVE_SPLIT_MAX_BATCH;
+    const dim3 grid(A.B), block(split ? 128 : 64);
 #define TPR_LAUNCH_WAVE(SS)                                                                                   \
     do {                                                                                                      \
         if (table) hipLaunchKernelGGL((tpr::wave_solve_kernel<SS, true>), grid, block, lds, stream, A);       \
         else hipLaunchKernelGGL((tpr::wave_solve_kernel<SS, false>), grid, block, lds, stream, A);            \
     } while (0)
+    if (split) {
+        if (table) hipLaunchKernelGGL((tpr::wave_solve_kernel<1, true, true>), grid, block, lds, stream, A);
+        else hipLaunchKernelGGL((tpr::wave_solve_kernel<1, false, true>), grid, block, lds, stream, A);
+        return TPR_E_OK;
+    }
     switch (slots) {
         case 1: TPR_LAUNCH_WAVE(1); break;
         case 2: TPR_LAUNCH_WAVE(2); break;
