@@ -14,7 +14,7 @@ cp gpurun_out/stress.log profiles/${R}_shortcut_vs_full_seidel_stress.log
 [ -f gpurun_out/hitrate.log ] && cp gpurun_out/hitrate.log profiles/${R}_shortcut_hit_rate.log
 [ -f gpurun_out/phases.log ] && cp gpurun_out/phases.log profiles/${R}_family3_cycle_breakdown.log
 for pair in feasible_check:feasible_sets_family3_check sd_check:toppra_sd_fused_check robust_check:robust_rows_across_lanes_check cert_dofs:family3_above_8_dof \
-            r3_stress:stress_round3_kernels wave_check:family4_parity_and_timings sliver_hunt:sliver_hunt mode_times:certificate_mode_times wave_phases:family4_cycle_breakdown param_pcr_check:param_spline_knot_parallel_check dense_check:dense_rows_check; do
+            r3_stress:stress_round3_kernels wave_check:family4_parity_and_timings pair_check:family5_parity_and_timings sliver_hunt:sliver_hunt mode_times:certificate_mode_times wave_phases:family4_cycle_breakdown param_pcr_check:param_spline_knot_parallel_check dense_check:dense_rows_check; do
   src=${pair%%:*}; dst=${pair##*:}
   [ -f gpurun_out/$src.log ] && grep -v amdgpu.ids gpurun_out/$src.log > profiles/${R}_$dst.log
 done

@@ -31,6 +31,7 @@ timeout 600 python tools/gpu_robust_check.py > gpurun_out/robust_check.log 2>&1;
 timeout 900 python tools/gpu_cert_dofs_check.py > gpurun_out/cert_dofs.log 2>&1; tail -9 gpurun_out/cert_dofs.log
 timeout 900 python tools/gpu_r3_stress.py ${STRESS_ROUNDS:-2} > gpurun_out/r3_stress.log 2>&1; tail -20 gpurun_out/r3_stress.log
 timeout 600 python tools/gpu_wave_check.py > gpurun_out/wave_check.log 2>&1; tail -12 gpurun_out/wave_check.log
+timeout 900 python tools/gpu_pair_check.py > gpurun_out/pair_check.log 2>&1; tail -16 gpurun_out/pair_check.log
 timeout 600 python tools/gpu_sliver_hunt.py > gpurun_out/sliver_hunt.log 2>&1; tail -3 gpurun_out/sliver_hunt.log
 timeout 300 python tools/gpu_mode_times.py > gpurun_out/mode_times.log 2>&1; cat gpurun_out/mode_times.log
 timeout 300 python tools/gpu_param_pcr_check.py > gpurun_out/param_pcr_check.log 2>&1; tail -4 gpurun_out/param_pcr_check.log
