@@ -38,7 +38,8 @@ def _family3(ks):
 
 def test_scratch_lds_and_registers_of_the_certified_lane_kernels(resources):
     """Per dof, over every instantiation (sd output, grid in LDS, discretisation, TOPPRAsd): no scratch at all up to 8 dof, at
-    most 512 B per lane at 9..13 dof (round 5 as built: 28 .. 448 B; the failure mode is 1.4 KB and more); LDS small enough for
+    most 512 B per lane at 9..12 dof and 640 B at 13 (round 6 as built: 0 .. 376 B, 13 dof's TOPPRAsd instantiation 524 B with the
+    flags that timing chose for that unit; the failure mode is 1.4 KB and more); LDS small enough for
     four blocks per CU (one wave per SIMD) -- 160 KB / 4; and a register count that still fits one wave per SIMD."""
     kr, ks = resources
     fam = _family3(ks)
@@ -47,15 +48,16 @@ def test_scratch_lds_and_registers_of_the_certified_lane_kernels(resources):
         scratch = max(r["scratch"] for r in rs)
         lds = max(r["lds"] for r in rs)
         regs = max(r["vgpr"] for r in rs)
-        assert scratch <= (0 if d <= 8 else 512), (kernel, d, "scratch bytes per lane", scratch)
+        assert scratch <= (0 if d <= 8 else 512 if d <= 12 else 640), (kernel, d, "scratch bytes per lane", scratch)
         assert lds <= 160 * 1024 // 4, (kernel, d, "LDS bytes per block", lds)
         assert regs <= 512, (kernel, d, "vector + accumulator registers", regs)
 
 
 # (dof, grid in LDS): instructions and divergent-region branches (s_cbranch_exec*) of cert_solve_kernel<dof, 64, no sd output, ...,
-# Interpolation, sound, not TOPPRAsd> as built in round 5, with 5 % / 10 % of headroom.  Round 4's pathological fetch took the 9-dof
-# kernel from 129 to 172 such branches.
-CEILINGS = {(7, 1): (10884, 123), (9, 0): (13329, 133), (12, 0): (17202, 155), (13, 0): (17652, 159)}
+# Interpolation, sound, not TOPPRAsd> as built in round 6 (7 dof: round 5's figures; 9..13 dof: with the transposed workspace's
+# prologue and the per-dof flags of build.py::CERT_UNIT_FLAGS), with 5 % / 10 % of headroom.  Round 4's pathological fetch took the
+# 9-dof kernel from 129 to 172 such branches.
+CEILINGS = {(7, 1): (10884, 123), (9, 0): (13329, 142), (12, 0): (18239, 167), (13, 0): (18784, 175)}
 
 
 @pytest.mark.parametrize("d,gl", sorted(CEILINGS))
