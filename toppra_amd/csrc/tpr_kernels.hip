@@ -440,9 +440,10 @@ int launch_cert_feasible(const tpr::BatchArgs &A, double *X, hipStream_t stream)
 }
 
 // TOPPRAsd on family 3: backward scan and both forward profiles in one launch
-int launch_cert_sd(const tpr::BatchArgs &A, double *xf, double *uf, double *xl, double *ul, hipStream_t stream) {
+int launch_cert_sd(const tpr::BatchArgs &A, double *xf, double *uf, double *xl, double *ul, double *dur, hipStream_t stream) {
     tpr::GroupArgs G{A.B, A.nseg, A.N, A.flags, A.coef, A.breaks, A.grid, A.vlim, A.alim,
                      A.sd_start, A.sd_end, A.sd2, nullptr, A.u, A.K, A.status, nullptr, 0, xf, uf, xl, ul};
+    G.sd_dur = dur;
     switch (A.d) {
 #ifndef TPR_CERT_DEV
         case 1: return cert_tu_rc(tpr_tu_cert_sd_launch_1(&G, stream));
@@ -874,7 +875,7 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
     int32_t *wstatus = nullptr, *wlist = nullptr;
     const size_t per = 2 * (N + 1) + 2 * N;
     // (every allocation joins S.owned as soon as it exists: an early return must not leak the ones before it)
-    if (S.err == hipSuccess) { S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * (per + (dalpha ? 0 : 1)) * sizeof(double) + 8, stream); if (S.err == hipSuccess) S.owned.push_back(ws); }
+    if (S.err == hipSuccess) { S.err = hipMallocAsync(reinterpret_cast<void **>(&ws), B * (per + 3) * sizeof(double) + 8, stream); if (S.err == hipSuccess) S.owned.push_back(ws); }
     if (S.err == hipSuccess) { S.err = hipMallocAsync(reinterpret_cast<void **>(&wlist), (B + 2) * sizeof(int32_t), stream); if (S.err == hipSuccess) S.owned.push_back(wlist); }
     if (S.err == hipSuccess && !A.status) {
         S.err = hipMallocAsync(reinterpret_cast<void **>(&wstatus), B * sizeof(int32_t) + 4, stream);
@@ -885,6 +886,8 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
     if (!dalpha) dalpha = ws + B * per;
     if (A.B > 0) {
         double *xf = ws, *uf = ws + B * (N + 1), *xl = ws + B * (2 * N + 1), *ul = ws + B * (3 * N + 2);
+        double *wdur = ws + B * (per + 1);  // [B][2]: the two profiles' durations, summed by family 3's forward scans
+        const double *dur_in = nullptr;
         tpr::BatchArgs Ab = A;
         Ab.backward_only = 1;
         // p->variant: 0 = auto; 2 / 3 force the rows-across-lanes scans / the certified lane kernel for both scans
@@ -892,7 +895,8 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
         if (fused) {
             // family 3: backward scan + fastest / slowest forward profiles in ONE launch (cert_solve_kernel<SDFWD>)
             if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 13, no strict mode");
-            if (int rc = launch_cert_sd(A, xf, uf, xl, ul, stream)) return rc;
+            if (int rc = launch_cert_sd(A, xf, uf, xl, ul, wdur, stream)) return rc;
+            dur_in = wdur;
         } else {
             // backward scan -> K and the controllability verdict (the time-optimal forward scan is not needed), then
             // the two forward scans on the rows-across-lanes kernel
@@ -904,6 +908,7 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
         tpr::SdBlendArgs G{A.B, A.N, A.flags, atol, A.grid, ddes, xf, uf, xl, ul, A.status,
                            A.sd2, A.sd, A.u, dalpha, A.status};
         const size_t finish_lds = 5 * (N + 1) * sizeof(double);
+        if (finish_lds <= kMaxDynamicLds) G.dur = dur_in;  // (the three-kernel path below computes its own)
         if (finish_lds <= kMaxDynamicLds) {
             // one wave per trajectory: durations, bisection and the blend from LDS-resident profiles
             hipLaunchKernelGGL(tpr::sd_finish_kernel, dim3(A.B), dim3(64), finish_lds, stream, G);
