@@ -42,8 +42,8 @@ def other_entries(B=65536, d=7, N=200):
     dv = [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]
     zero = torch.zeros(B, dtype=torch.float64, device=dev)
 
-    def timed(fn, reps=3):
-        fn(); torch.cuda.synchronize()
+    def timed(fn, reps=10):  # wall time per call over 10 calls after two warm-up calls (the first launches of a process run 5-10 % slow)
+        fn(); fn(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
