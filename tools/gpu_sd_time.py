@@ -1,4 +1,4 @@
-"""TOPPRAsd at the headline shape (65536 x 7 x 200, device tensors in and out): wall time per call, the share of trajectories that
+"""TOPPRAsd at the headline shape (65536 x 7 x 200, device tensors in and out; another dof as argv[1]): wall time per call, the share of trajectories that
 bisect, and parity of the fused path (family 3: durations summed in the forward scans) with the rows-across-lanes kernels
 (sd_finish_kernel's own duration passes) on a sub-batch."""
 import os, sys, time
@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toppra_amd import batch as tb, _capi
 _capi.init(0)
-B, d, N = 65536, 7, 200
+B, d, N = 65536, (int(sys.argv[1]) if len(sys.argv) > 1 else 7), 200
 data = tb.make_synthetic_batch(B, d, N)
 dev = torch.device("cuda", 0)
 dv = [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]

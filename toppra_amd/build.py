@@ -50,9 +50,15 @@ CERT_DOFS = tuple(range(1, CERT_MAX_DOF + 1))
 
 
 # Per-dof compiler flags of kernel family 3's units, chosen by TIMING among the code generations that pass the check of
-# codegen_check.py (65536 x d x 200, profiles/r06_dofs_matrix.log): above 8 dof the kernels fill the register file, and what the
-# allocator makes of them moves by tens of percent with flags that change nothing else.
-CERT_UNIT_FLAGS = {9: ["-fno-slp-vectorize"], 10: ["-fno-slp-vectorize"], 13: ["-mllvm", "-greedy-reverse-local-assignment=1"]}
+# codegen_check.py (65536 x d x 200, profiles/r06_dofs_matrix.log, profiles/r06_sched_flags_9_13.log): above 8 dof the kernels fill
+# the register file, and what the scheduler and the allocator make of them moves by tens of percent with flags that change nothing
+# else.  Round 6, second session: the pre-RA scheduler's direction and its register-pressure trackers matter most -- top-down
+# list scheduling takes the 12-dof solve from 4.62 to 3.98 ms and (with -fno-slp-vectorize) the 13-dof one from 8.03 to 5.32 ms
+# (scratch per lane 328 -> 132 B); the AMDGPU pressure trackers take 10 dof from 2.97 to 2.80 ms.
+_TRACKERS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
+_TOPDOWN = ["-mllvm", "-misched-prera-direction=topdown"]
+CERT_UNIT_FLAGS = {9: ["-fno-slp-vectorize"] + _TRACKERS, 10: ["-fno-slp-vectorize"] + _TRACKERS, 12: _TOPDOWN,
+                   13: _TOPDOWN + ["-fno-slp-vectorize"]}
 # ... and what the build tries next, in this order, when a unit's code shows a vector copy above an exec restore
 # (profiles/r06_miscompile_root_cause.md): the first clean code generation is linked, none is an error.
 CERT_FLAG_LADDER = [[], ["-fno-slp-vectorize"], ["-mllvm", "-greedy-reverse-local-assignment=1"],
