@@ -57,7 +57,9 @@ CERT_DOFS = tuple(range(1, CERT_MAX_DOF + 1))
 # (scratch per lane 328 -> 132 B); the AMDGPU pressure trackers take 10 dof from 2.97 to 2.80 ms.
 _TRACKERS = ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
 _TOPDOWN = ["-mllvm", "-misched-prera-direction=topdown"]
-CERT_UNIT_FLAGS = {9: ["-fno-slp-vectorize"] + _TRACKERS, 10: ["-fno-slp-vectorize"] + _TRACKERS, 12: _TOPDOWN,
+CERT_UNIT_FLAGS = {8: _TOPDOWN + ["-fno-slp-vectorize"],  # (8 dof: 2.15 / 2.29 / 3.08 -> 2.11 / 2.19 / 2.94 ms solve / feasible sets / TOPPRAsd;
+                   # up to 7 dof nothing moves by more than 1 - 2 %: profiles/r06_sched_flags_6_8.log)
+                   9: ["-fno-slp-vectorize"] + _TRACKERS, 10: ["-fno-slp-vectorize"] + _TRACKERS, 12: _TOPDOWN,
                    13: _TOPDOWN + ["-fno-slp-vectorize"]}
 # ... and what the build tries next, in this order, when a unit's code shows a vector copy above an exec restore
 # (profiles/r06_miscompile_root_cause.md): the first clean code generation is linked, none is an error.
