@@ -19,7 +19,7 @@ def main():
     os.makedirs(common, exist_ok=True); os.makedirs(var, exist_ok=True)
     if not os.listdir(common):
         # the product's objects of every other unit (cert units up to 8 dof; the library dispatches 9..13 to family 2 then)
-        os.environ["TPR_BUILD_CERT_MAX_DOF"] = "8" if dof <= 8 else "13"
+        os.environ["TPR_BUILD_CERT_MAX_DOF"] = "8" if dof <= 8 else str(max(13, dof))
         os.environ["TPR_BUILD_KEEP_OBJS"] = common
         import importlib; importlib.reload(B)
         B.build(out=os.path.join(out, "product.so"), verbose=False)

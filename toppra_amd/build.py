@@ -40,12 +40,13 @@ def stale():
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in deps())
 
 
-# kernel family 3: one translation unit per dof (csrc/tpr_cert_tu.hip), 1..13 (slim blocks above 8 dof).  Round 4's
+# kernel family 3: one translation unit per dof (csrc/tpr_cert_tu.hip), 1..14 (slim blocks above 8 dof; 14 dof stores K without
+# staging, which keeps its block under 160 KB / 4).  Round 4's
 # trace-following certificates first pushed the 9..13-dof instantiations far out of the register file (1.4 - 2.4 KB of scratch
 # per lane: 10.6 - 22 ms at 65536 x d x 200); the cause was one conditionally-needed load in CertStage::fetch that the compiler
 # sank into divergent regions (tpr_cert_lane.hip.inc), and without it they are back at 0 - 0.7 KB: 3.0 / 4.6 / 7.8 / 7.7 /
 # 10.9 ms at 9..13 dof against 10.2 - 12.0 for the rows-across-lanes kernels.
-CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "13"))
+CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "14"))
 CERT_DOFS = tuple(range(1, CERT_MAX_DOF + 1))
 
 
@@ -60,7 +61,8 @@ _TOPDOWN = ["-mllvm", "-misched-prera-direction=topdown"]
 CERT_UNIT_FLAGS = {8: _TOPDOWN + ["-fno-slp-vectorize"],  # (8 dof: 2.15 / 2.29 / 3.08 -> 2.11 / 2.19 / 2.94 ms solve / feasible sets / TOPPRAsd;
                    # up to 7 dof nothing moves by more than 1 - 2 %: profiles/r06_sched_flags_6_8.log)
                    9: ["-fno-slp-vectorize"] + _TRACKERS, 10: ["-fno-slp-vectorize"] + _TRACKERS, 12: _TOPDOWN,
-                   13: _TOPDOWN + ["-fno-slp-vectorize"]}
+                   13: _TOPDOWN + ["-fno-slp-vectorize"],
+                   14: _TRACKERS}  # (14 dof, new in round 6: 7.7 ms against 12.1 base and 12.1 for the rows-across-lanes kernels; profiles/r06_dof14_flags.log)
 # ... and what the build tries next, in this order, when a unit's code shows a vector copy above an exec restore
 # (profiles/r06_miscompile_root_cause.md): the first clean code generation is linked, none is an error.
 CERT_FLAG_LADDER = [[], ["-fno-slp-vectorize"], ["-mllvm", "-greedy-reverse-local-assignment=1"],
