@@ -63,6 +63,18 @@ CERT_UNIT_FLAGS = {8: _TOPDOWN + ["-fno-slp-vectorize"],  # (8 dof: 2.15 / 2.29 
                    9: ["-fno-slp-vectorize"] + _TRACKERS, 10: ["-fno-slp-vectorize"] + _TRACKERS, 12: _TOPDOWN,
                    13: _TOPDOWN + ["-fno-slp-vectorize"],
                    14: _TRACKERS}  # (14 dof, new in round 6: 7.7 ms against 12.1 base and 12.1 for the rows-across-lanes kernels; profiles/r06_dof14_flags.log)
+# A dof whose three entry points (1 = fused solve / backward scan, 2 = feasible sets, 3 = TOPPRAsd; csrc/tpr_cert_tu.hip,
+# -DTPR_TU_PART) want different flags is compiled as three units: {dof: {part: flags}}.  Timing choices as above.
+_MAXILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+_REVERSE = ["-mllvm", "-greedy-reverse-local-assignment=1"]
+CERT_UNIT_PARTS = {
+    # 7 dof (the headline shape): the solve kernel does not react to any of 28 settings; feasible sets 1.86 -> 1.81 ms with the
+    # max-ILP strategy, TOPPRAsd 2.59 -> 2.48 ms per call top-down without SLP (profiles/r06_part_flags.log)
+    7: {1: [], 2: _MAXILP, 3: _TOPDOWN + ["-fno-slp-vectorize"]},
+    # 13 dof: solve 8.0 -> 5.3 ms top-down without SLP, which costs the feasible-sets kernel 3 % (8.58 plain) and leaves
+    # TOPPRAsd at 9.6 ms where the pressure trackers + reverse local assignment reach 7.3
+    13: {1: _TOPDOWN + ["-fno-slp-vectorize"], 2: [], 3: _TRACKERS + _REVERSE},
+}
 # ... and what the build tries next, in this order, when a unit's code shows a vector copy above an exec restore
 # (profiles/r06_miscompile_root_cause.md): the first clean code generation is linked, none is an error.
 CERT_FLAG_LADDER = [[], ["-fno-slp-vectorize"], ["-mllvm", "-greedy-reverse-local-assignment=1"],
@@ -95,6 +107,14 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
             only_dofs = os.environ.get("TPR_BUILD_ONLY_CERT_DOFS", "").split()
             if not only_dofs or str(d) in only_dofs:
                 extra += os.environ.get("TPR_BUILD_CERT_FLAGS", "").split()
+            parts = CERT_UNIT_PARTS.get(d)
+            if parts is None and str(d) in os.environ.get("TPR_BUILD_SPLIT_DOFS", "").split():  # (experiments: split, the unit's flags on every part)
+                parts = {k: CERT_UNIT_FLAGS.get(d, []) for k in (1, 2, 3)}
+            if not extra and not defines and parts:  # (the product's split unit: one object per entry point)
+                for part, pflags in sorted(parts.items()):
+                    jobs.append((os.path.join(CSRC, "tpr_cert_tu.hip"), os.path.join(tmp, "cert%dp%d.o" % (d, part)),
+                                 ["-DTPR_TU_D=%d" % d, "-DTPR_TU_PART=%d" % part] + list(pflags)))
+                continue
             if not extra and not defines:  # (no experiment on this dof: the product's flags for it)
                 extra = list(CERT_UNIT_FLAGS.get(d, []))
             jobs.append((os.path.join(CSRC, "tpr_cert_tu.hip"), os.path.join(tmp, "cert%d.o" % d), ["-DTPR_TU_D=%d" % d] + extra))
@@ -133,7 +153,7 @@ def _compile_and_link(target, flags, defines, verbose, single_tu, cert_max_dof=N
             skey = hashlib.sha256((dep_hash.hexdigest() + os.path.basename(src)).encode()).hexdigest()[:12]
             name = os.path.basename(obj)[:-2]
             cached = os.path.join(cache, "%s_%s_%s.o" % (name, fkey, skey))
-            stale_ok = only and name.startswith("cert") and name[4:] not in only
+            stale_ok = only and name.startswith("cert") and name[4:].split("p")[0] not in only
             if stale_ok and not os.path.exists(cached):
                 olds = sorted((f for f in os.listdir(cache) if f.startswith("%s_%s_" % (name, fkey)) and f.endswith(".o")),
                               key=lambda f: os.path.getmtime(os.path.join(cache, f)))

@@ -14,7 +14,13 @@
 #include "tpr_cert.hip.inc"
 
 #ifndef TPR_TU_D
-#error "compile with -DTPR_TU_D=<dof 1..13>"
+#error "compile with -DTPR_TU_D=<dof 1..14>"
+#endif
+// A dof's unit can be split by entry point (build.py::CERT_UNIT_PARTS): 1 = the fused solve / backward scan, 2 = feasible sets,
+// 3 = TOPPRAsd; 0 = all three in one unit.  Above 8 dof the three kernels want DIFFERENT scheduler flags (the switch that takes
+// the 13-dof solve from 8.0 to 5.2 ms takes its feasible-sets kernel from 9.3 to 10.8), and flags are per translation unit.
+#ifndef TPR_TU_PART
+#define TPR_TU_PART 0
 #endif
 
 // The certificates follow the reference's whole pivot trace (tpr_cert_lane.hip.inc: cert_propose_sound & co) -- the only mode
@@ -53,6 +59,7 @@ struct TwsScope {
 #define TPR_TU_CAT2(a, b) a##b
 #define TPR_TU_CAT(a, b) TPR_TU_CAT2(a, b)
 
+#if TPR_TU_PART == 0 || TPR_TU_PART == 1
 // Launch the certified lane kernel for TPR_TU_D dof: the fused solve, or the backward scan alone (G.backward_only).
 // Returns 0, or -1 when the launch geometry cannot be met (never for supported shapes).
 extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, hipStream_t stream) {
@@ -90,7 +97,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_laun
 #undef TPR_LAUNCH_CERT
     return 0;
 }
+#endif
 
+#if TPR_TU_PART == 0 || TPR_TU_PART == 2
 // compute_feasible_sets on the certified lane design (cert_feasible_kernel): X [B][N+1][2].
 extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feasible_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, double *X, hipStream_t stream) {
     constexpr int D = TPR_TU_D, BS = 64;
@@ -119,7 +128,9 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_feas
 #undef TPR_LAUNCH_FEAS
     return 0;
 }
+#endif
 
+#if TPR_TU_PART == 0 || TPR_TU_PART == 3
 // TOPPRAsd: backward scan + the fastest / slowest forward profiles in one launch (cert_solve_kernel<..., SDFWD = true>).
 extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_launch_, TPR_TU_D)(const tpr::GroupArgs *Gp, hipStream_t stream) {
     constexpr int D = TPR_TU_D, BS = 64;
@@ -148,4 +159,5 @@ extern "C" __attribute__((visibility("hidden"))) int TPR_TU_CAT(tpr_tu_cert_sd_l
 #undef TPR_LAUNCH_SD
     return 0;
 }
+#endif
 
