@@ -62,7 +62,7 @@ CERT_UNIT_FLAGS = {8: _TOPDOWN + ["-fno-slp-vectorize"],  # (8 dof: 2.15 / 2.29 
                    # up to 7 dof nothing moves by more than 1 - 2 %: profiles/r06_sched_flags_6_8.log)
                    9: ["-fno-slp-vectorize"] + _TRACKERS, 10: ["-fno-slp-vectorize"] + _TRACKERS, 12: _TOPDOWN,
                    13: _TOPDOWN + ["-fno-slp-vectorize"],
-                   14: _TRACKERS}  # (14 dof, new in round 6: 7.7 ms against 12.1 base and 12.1 for the rows-across-lanes kernels; profiles/r06_dof14_flags.log)
+                   14: _TRACKERS}  # (12 .. 14 dof are split by entry point: CERT_UNIT_PARTS below; these are the flags of an unsplit experiment build)
 # A dof whose three entry points (1 = fused solve / backward scan, 2 = feasible sets, 3 = TOPPRAsd; csrc/tpr_cert_tu.hip,
 # -DTPR_TU_PART) want different flags is compiled as three units: {dof: {part: flags}}.  Timing choices as above.
 _MAXILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
@@ -71,9 +71,12 @@ CERT_UNIT_PARTS = {
     # 7 dof (the headline shape): the solve kernel does not react to any of 28 settings; feasible sets 1.86 -> 1.81 ms with the
     # max-ILP strategy, TOPPRAsd 2.59 -> 2.48 ms per call top-down without SLP (profiles/r06_part_flags.log)
     7: {1: [], 2: _MAXILP, 3: _TOPDOWN + ["-fno-slp-vectorize"]},
-    # 13 dof: solve 8.0 -> 5.3 ms top-down without SLP, which costs the feasible-sets kernel 3 % (8.58 plain) and leaves
-    # TOPPRAsd at 9.6 ms where the pressure trackers + reverse local assignment reach 7.3
-    13: {1: _TOPDOWN + ["-fno-slp-vectorize"], 2: [], 3: _TRACKERS + _REVERSE},
+    # 12 .. 14 dof (profiles/r06_part_flags_round2.log, on the code with the smaller exchange area): solve / feasible sets / TOPPRAsd
+    # 12: 3.74 / 6.86 / 5.87 ms, 13: 4.45 / 8.20 / 6.44 ms, 14: 6.97 / 7.46 / 10.6 ms -- one flag set per unit costs up to 2 x on
+    # one of the three (13 dof, TOPPRAsd: 6.4 ms with trackers + reverse assignment, 11.8 top-down + reverse, which is the solve's best)
+    12: {1: _TOPDOWN + _REVERSE, 2: _REVERSE, 3: _TOPDOWN},
+    13: {1: _TOPDOWN + _REVERSE, 2: _TOPDOWN, 3: _TRACKERS + _REVERSE},
+    14: {1: _TRACKERS + ["-fno-slp-vectorize"], 2: _TRACKERS + _REVERSE, 3: _TRACKERS},
 }
 # ... and what the build tries next, in this order, when a unit's code shows a vector copy above an exec restore
 # (profiles/r06_miscompile_root_cause.md): the first clean code generation is linked, none is an error.
