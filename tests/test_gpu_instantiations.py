@@ -69,3 +69,50 @@ def test_every_feasible_sets_and_toppra_sd_instantiation(gpu, d):
             assert np.array_equal(a["status"], b["status"]), what
             for k in ("K", "sd2", "sd", "u", "alpha"):
                 assert np.array_equal(a[k], b[k], equal_nan=True), what + (k,)
+
+
+def _tight_joint_problem(d, seed):
+    """4 d trajectories in which ONE joint's rows bind the stage LPs: joint j % d gets acceleration limits a fiftieth of the others'
+    -- both signs, the upper one only (the + rows: c = -amax), the lower one only (the - rows: c = amin), or both with a velocity
+    limit that binds as well.  Round 6's 15-dof incident (profiles/r06_dof15_unsplit_unit_incident.log) was a register tuple of ONE
+    joint's limits restored with a stale low dword: wrong only where that joint's + row bound the forward LP, i.e. on a fifth of a
+    random batch at isolated stages.  Here every joint's every kind of row binds at most stages of some trajectory."""
+    Bt = 4 * d
+    data = batch.make_synthetic_batch(Bt, d, N, seed=seed)
+    alim = np.array(data["alim"], dtype=np.float64)   # [B][d][2] = (amin, amax)
+    vlim = np.array(data["vlim"], dtype=np.float64)
+    for j in range(Bt):
+        k, kind = j % d, j // d
+        if kind in (0, 1, 3):
+            alim[j, k, 1] *= 0.02
+        if kind in (0, 2, 3):
+            alim[j, k, 0] *= 0.02
+        if kind == 3:
+            vlim[j, k] *= 0.05
+    return dict(data, alim=alim, vlim=vlim)
+
+
+@pytest.mark.parametrize("d", range(1, 15))
+def test_every_joints_rows_bind_somewhere(gpu, oracle, d):
+    data = _tight_joint_problem(d, 900 + d)
+    grid = data["grid"]
+    desired = np.random.default_rng(50 + d).uniform(2.0, 40.0, size=4 * d)
+    for interp in (True, False):
+        args = (data["coef"], data["breaks"], grid, data["vlim"], data["alim"], None, None, interp)
+        want = batch.solve_batch(*args, variant=2)
+        got = batch.solve_batch(*args, variant=3)
+        ref = oracle.solve_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], None, None,
+                                 flags=oracle.DEFAULT_FLAGS if interp else oracle.DEFAULT_FLAGS & ~oracle.FLAG_INTERP, nthreads=4)
+        assert (ref["status"] == 0).mean() > 0.5, (d, interp)
+        for k in ("status", "K", "sd2", "u"):
+            assert np.array_equal(want[k], ref[k], equal_nan=True), (d, interp, "family 2 vs oracle", k)
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (d, interp, "family 3 vs oracle", k)
+        X2 = batch.feasible_sets_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], interp, variant=2)
+        X3 = batch.feasible_sets_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], interp, variant=3)
+        assert np.array_equal(X3, X2, equal_nan=True), (d, interp, "X")
+        a = batch.solve_desired_duration_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], desired, None, None,
+                                               variant=2, interpolation=interp)
+        b = batch.solve_desired_duration_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], desired, None, None,
+                                               variant=3, interpolation=interp)
+        for k in ("status", "K", "sd2", "sd", "u", "alpha"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), (d, interp, "TOPPRAsd", k)
