@@ -107,6 +107,10 @@ def test_every_joints_rows_bind_somewhere(gpu, oracle, d):
         for k in ("status", "K", "sd2", "u"):
             assert np.array_equal(want[k], ref[k], equal_nan=True), (d, interp, "family 2 vs oracle", k)
             assert np.array_equal(got[k], ref[k], equal_nan=True), (d, interp, "family 3 vs oracle", k)
+        for v in (1, 4) + ((5,) if d <= 7 else ()):  # (the other families on the same batch: one trajectory per lane / wave, two per wave)
+            other = batch.solve_batch(*args, variant=v)
+            for k in ("status", "K", "sd2", "u"):
+                assert np.array_equal(other[k], ref[k], equal_nan=True), (d, interp, "family %d vs oracle" % v, k)
         X2 = batch.feasible_sets_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], interp, variant=2)
         X3 = batch.feasible_sets_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], interp, variant=3)
         assert np.array_equal(X3, X2, equal_nan=True), (d, interp, "X")
