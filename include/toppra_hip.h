@@ -83,7 +83,7 @@ typedef struct tpr_problem {
     int32_t B, d, nseg, N;
     int32_t flags;
     int32_t variant; /* kernel selection: 0 = auto, 1 = generic lane-per-trajectory, 2 = rows-across-lanes,
-                        3 = lane-per-trajectory certificates (d <= 14; sd2, u, status required),
+                        3 = lane-per-trajectory certificates (d <= 15; sd2, u, status required),
                         4 = one trajectory per wave (the latency kernel: any dof, N <= 1480; auto for
                             small batches),
                         5 = two trajectories per wave, 32 lanes each (the fused solve for 1..7 dof, N <= ~800;
@@ -147,7 +147,7 @@ int tpr_solve_batch(const tpr_problem *p, const tpr_result *r, void *stream);
  * "slowest" forward scans, the duration bisection on their convex combination (absolute tolerance
  * atol, reference default 1e-5) and the blended sd^2 / u.  desired [B] seconds; alpha [B] (may be
  * NULL) receives the blend factor.  Same result struct and status codes as tpr_solve_batch; up to 16 dof.
- * p->variant: 0 = auto -- from 9216 trajectories (9..14 dof: 14336 .. 34816) the certified lane kernel runs the
+ * p->variant: 0 = auto -- from 9216 trajectories (9..15 dof: 14336 .. 36864) the certified lane kernel runs the
  * backward scan and both forward profiles in ONE launch, the rows-across-lanes kernels otherwise; 2 / 3 force one.
  * Bisection and blend: one wave per trajectory.                                                      */
 int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired, double atol,
@@ -175,7 +175,7 @@ int tpr_controllable_sets_batch(const tpr_problem *p, const double *sdmin, const
 
 /* Replaces ReachabilityAlgorithm.compute_feasible_sets (reachability_algorithm.py:131-164).
  * X [B][N+1][2].  p->variant: 0 = auto (one wave per trajectory for a handful of trajectories, above 16 dof or with
- * p->active; the certified lane kernel from 8192 trajectories up to 8 dof, 14336 .. 34816 at 9 .. 14 dof; rows across lanes
+ * p->active; the certified lane kernel from 8192 trajectories up to 8 dof, 14336 .. 36864 at 9 .. 15 dof; rows across lanes
  * otherwise), 1 / 2 / 3 / 4 force a kernel family.  TPR_STRICT_SEIDEL / TPR_SOUND_CERTIFICATES as tpr_solve_batch.   */
 int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream);
 

@@ -19,7 +19,7 @@ def _variants(d, interp, has_vel=True):
     # 4 one trajectory per wave (the latency kernel: every dof and constraint set)
     # Collocation: the interpolation blocks are disabled rows (families 2, 4) / null rows (family 3)
     # (family 3 is instantiated up to 8 dof, family 2 up to 16)
-    return [1, 2, 3, 4] if d <= 14 else ([1, 2, 4] if d <= 16 else [1, 4])
+    return [1, 2, 3, 4] if d <= 15 else ([1, 2, 4] if d <= 16 else [1, 4])
 
 
 @pytest.mark.parametrize("name", batch_fixtures())
@@ -37,7 +37,7 @@ def test_batch_fixture(gpu, name):
     if "X" in fx:
         assert_same(batch.feasible_sets_batch(coef, breaks, grid, vlim, alim, interp), fx["X"], "X")
         # ... and through every kernel family that serves it (3: the certified lane kernel, fast and sound certificates)
-        for kw in ([dict(variant=2)] if coef.shape[3] <= 16 else []) + [dict(variant=4)] + ([dict(variant=3)] if coef.shape[3] <= 14 and alim is not None else []) + ([dict(variant=3, sound=True)] if coef.shape[3] <= 14 and alim is not None else []):
+        for kw in ([dict(variant=2)] if coef.shape[3] <= 16 else []) + [dict(variant=4)] + ([dict(variant=3)] if coef.shape[3] <= 15 and alim is not None else []) + ([dict(variant=3, sound=True)] if coef.shape[3] <= 15 and alim is not None else []):
             assert_same(batch.feasible_sets_batch(coef, breaks, grid, vlim, alim, interp, **kw), fx["X"], "X %s" % kw)
     # compute_controllable_sets(sd_end, sd_end) is the K of the parameterization
     K = batch.controllable_sets_batch(coef, breaks, grid, vlim, alim, sd1, sd1, interp)

@@ -5,7 +5,7 @@ code made ONE instantiation return wrong results on every input (round 3: feasib
 profiles of <5 dof, TOPPRAsd>) while its neighbours stayed right.  Such a defect is input-independent, so a small random batch
 through each (dof, sd output, grid in LDS or per trajectory, Interpolation or Collocation) instantiation of cert_solve_kernel,
 cert_feasible_kernel and the TOPPRAsd launch -- compared bit for bit with the rows-across-lanes kernels, which share no device code
-with them beyond the row generation -- is a cheap net under all of them (14 dofs x 8 + 14 x 4 + 14 x 4 launches of 96 trajectories).
+with them beyond the row generation -- is a cheap net under all of them (15 dofs x 8 + 15 x 4 + 15 x 4 launches of 96 trajectories).
 Round 6: the net is self-standing -- per dof one 96 x 48 batch of each discretisation also goes through the CPU restatement of
 the reference (oracle/), so a defect in what the two kernel families SHARE (row generation, the division / square-root
 sequences of tpr_device.hpp) cannot pass it either.  What a failure here usually is: profiles/r06_miscompile_root_cause.md."""
@@ -30,7 +30,7 @@ def _problem(d, seed, per_traj_grid):
     return data, grid, sd0, sd1
 
 
-@pytest.mark.parametrize("d", range(1, 15))
+@pytest.mark.parametrize("d", range(1, 16))
 def test_every_solve_instantiation(gpu, oracle, d):
     for per_traj_grid in (False, True):
         data, grid, sd0, sd1 = _problem(d, 700 + d, per_traj_grid)
@@ -52,7 +52,7 @@ def test_every_solve_instantiation(gpu, oracle, d):
                     assert np.array_equal(ref[k], want[k], equal_nan=True), (d, interp, "oracle", k)
 
 
-@pytest.mark.parametrize("d", range(1, 15))
+@pytest.mark.parametrize("d", range(1, 16))
 def test_every_feasible_sets_and_toppra_sd_instantiation(gpu, d):
     for per_traj_grid in (False, True):
         data, grid, sd0, sd1 = _problem(d, 800 + d, per_traj_grid)
@@ -92,7 +92,7 @@ def _tight_joint_problem(d, seed):
     return dict(data, alim=alim, vlim=vlim)
 
 
-@pytest.mark.parametrize("d", range(1, 15))
+@pytest.mark.parametrize("d", range(1, 16))
 def test_every_joints_rows_bind_somewhere(gpu, oracle, d):
     data = _tight_joint_problem(d, 900 + d)
     grid = data["grid"]

@@ -143,7 +143,7 @@ def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
     args = (data["coef"], data["breaks"], data["grid"], vlim, alim, None, sd1, interp)
     lane = batch.solve_batch(*args, variant=1)
     kws = [dict(variant=2), dict(variant=2, strict=True), dict(), dict(variant=4), dict(variant=4, strict=True)]
-    if alim is not None and d <= 14:
+    if alim is not None and d <= 15:
         kws.append(dict(variant=3))  # the certified lane kernel: Interpolation and Collocation, velocity optional
     for kw in kws:
         got = batch.solve_batch(*args, **kw)
@@ -158,7 +158,7 @@ def test_fast_kernels_serve_every_constraint_set(gpu, oracle, B, d, N, mode):
     assert X.shape == (64, N + 1, 2) and not np.isnan(X).any()
 
 
-@pytest.mark.parametrize("d", [9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("d", [9, 10, 11, 12, 13, 14, 15])
 def test_certified_lane_kernel_above_8_dof(gpu, oracle, d):
     """Family 3 serves 9..13 dof too (slim blocks, internal row numbering with a block stride of 16, three mask words for the
     80 row numbers), with the same trace-following certificates as below -- there is no other mode: solve (scaled paths,
@@ -263,7 +263,7 @@ def test_against_the_references_own_compiled_solver(gpu, d, N, seed):
         vel, acc = rb.constraint_tuples(coef[k], data["breaks"], data["grid"], data["vlim"][k], data["alim"][k])
         w = rb.make_wrapper([rb.PrecomputedConstraint(vel, False), rb.PrecomputedConstraint(acc, True)], None, data["grid"])
         ref.append(rb.parameterization(w, float(sd0[k]), float(sd1[k])))
-    kws = [dict(variant=1), dict(variant=2), dict(variant=4), dict()] + ([dict(variant=3)] if d <= 14 else [])
+    kws = [dict(variant=1), dict(variant=2), dict(variant=4), dict()] + ([dict(variant=3)] if d <= 15 else [])
     for kw in kws:
         got = batch.solve_batch(coef, data["breaks"], data["grid"], data["vlim"], data["alim"], sd0, sd1, want_sd=True, **kw)
         for k in range(B):
@@ -295,7 +295,7 @@ def test_sets_against_the_references_own_compiled_solver(gpu, d, N, seed):
         Xr.append(rb.feasible_sets(rb.make_wrapper(cons, None, data["grid"])))
         Kr.append(rb.controllable_sets(rb.make_wrapper(cons, None, data["grid"]), float(lo[k]), float(hi[k])))
     args = (coef, data["breaks"], data["grid"], data["vlim"], data["alim"])
-    for kw in [dict(variant=1), dict(variant=2), dict(variant=4), dict()] + ([dict(variant=3)] if d <= 14 else []):
+    for kw in [dict(variant=1), dict(variant=2), dict(variant=4), dict()] + ([dict(variant=3)] if d <= 15 else []):
         X = batch.feasible_sets_batch(*args, True, **kw)
         K = batch.controllable_sets_batch(*args, lo, hi, True, **kw)
         for k in range(B):

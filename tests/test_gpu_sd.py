@@ -21,7 +21,7 @@ def test_sd_fixture(gpu, name):
     ok = fx["status"] == 0
     assert np.any(out["alpha"][ok] == 1.0) and np.any((out["alpha"][ok] > 0) & (out["alpha"][ok] < 1))
     # ... and through each kernel family: rows across lanes for both scans (2), the fused certified lane launch (3, <= 13 dof)
-    for variant in [2] + ([3] if fx["coef"].shape[3] <= 14 else []):
+    for variant in [2] + ([3] if fx["coef"].shape[3] <= 15 else []):
         got = batch.solve_desired_duration_batch(fx["coef"], fx["breaks"], fx["grid"], fx["vlim"], fx["alim"],
                                                  fx["desired"], fx["sd_start"], fx["sd_end"], variant=variant)
         for k in ("K", "sd", "u", "sd2", "alpha"):

@@ -43,7 +43,7 @@ def test_scratch_lds_and_registers_of_the_certified_lane_kernels(resources):
     four blocks per CU (one wave per SIMD) -- 160 KB / 4; and a register count that still fits one wave per SIMD."""
     kr, ks = resources
     fam = _family3(ks)
-    assert {d for (_, d) in fam} == set(range(1, 15)), sorted(fam)
+    assert {d for (_, d) in fam} == set(range(1, 16)), sorted(fam)
     for (kernel, d), rs in sorted(fam.items()):
         scratch = max(r["scratch"] for r in rs)
         lds = max(r["lds"] for r in rs)

@@ -38,7 +38,7 @@ def check(label, got, want, keys):
 
 def main():
     quick = "--quick" in sys.argv
-    dofs = (9, 14) if quick else range(9, 15)   # (family 3 is instantiated up to 14 dof)
+    dofs = (9, 15) if quick else range(9, 16)   # (family 3 is instantiated up to 15 dof)
     for d in dofs:
         B, N = 1500, 60
         data = tb.make_synthetic_batch(B, d, N, seed=800 + d)
@@ -65,7 +65,7 @@ def main():
                 got = tb.solve_desired_duration_batch(*args, desired, variant=3, **kw)
                 check("d%d %-11s TOPPRAsd v3 vs v2" % (d, name), got, want, ("K", "sd2", "sd", "u", "status", "alpha"))
     dev = torch.device("cuda", 0)
-    for d in ((9, 14) if quick else (8, 9, 10, 11, 12, 13, 14)):
+    for d in ((9, 15) if quick else (8, 9, 10, 11, 12, 13, 14, 15)):
         data = tb.make_synthetic_batch(65536, d, 200)
         dv = [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]
         out = tb.solve_batch(*dv, variant=2)
@@ -76,7 +76,7 @@ def main():
         print("time     65536 x %2d x 200: family 3 %.3f ms, family 2 %.3f ms, identical %s" % (d, ms3, ms2, same), flush=True)
         del dv, out, out3
     # above family 3's range: rows across 16 lanes (family 2) up to 16 dof, one trajectory per wave (family 4) up to 32
-    for d, B in (() if quick else ((15, 65536), (16, 65536), (24, 16384), (32, 16384))):
+    for d, B in (() if quick else ((16, 65536), (24, 16384), (32, 16384))):
         data = tb.make_synthetic_batch(B, d, 200)
         dv = [torch.from_numpy(np.ascontiguousarray(data[k])).to(dev) for k in ("coef", "breaks", "grid", "vlim", "alim")]
         out = tb.solve_batch(*dv)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from toppra_amd import batch as tb, _capi
 _capi.init(0)
 dev = torch.device("cuda", 0)
-for d in (int(a) for a in sys.argv[1:]) if len(sys.argv) > 1 else range(9, 15):
+for d in (int(a) for a in sys.argv[1:]) if len(sys.argv) > 1 else range(9, 16):
     row = []
     for B in (8192, 12288, 16384, 20480, 24576, 28672, 32768, 40960, 49152):
         data = tb.make_synthetic_batch(B, d, 200)

@@ -6,7 +6,7 @@ joints that stand still, non-uniform knots and grids, non-zero boundary velociti
 
   feasible sets   certified lane kernel (variant 3, fast and sound)      vs  rows across lanes, strict (full iteration)
   TOPPRAsd        fused certified launch + wave-per-trajectory finish    vs  rows across lanes for both scans
-  solve 9-14 dof  certified lane kernel (fast and sound)                 vs  rows across lanes, strict
+  solve 9-15 dof  certified lane kernel (fast and sound)                 vs  rows across lanes, strict
 
   python tools/gpu_r3_stress.py [rounds]
 """
@@ -84,18 +84,18 @@ for rnd in range(ROUNDS):
         tally("TOPPRAsd, %s" % fam, B, bad)
         print("round %d %-9s B=%d d=%d N=%d: feasible / TOPPRAsd done; TOPPRAsd mismatching %d, bisected %.2f, ok %.2f"
               % (rnd, fam, B, d, N, int(bad.sum()), float(((want["alpha"] > 0) & (want["alpha"] < 1)).mean()), float((want["status"] == 0).mean())), flush=True)
-    for s, d in enumerate((9, 10, 11, 12, 13, 14)):
+    for s, d in enumerate((9, 10, 11, 12, 13, 14, 15)):
         for fam, (args, sd0, sd1, rng) in (("scaled", scaled(100 + 10 * rnd + s, 32768, d, 100)), ("irregular", irregular(100 + 10 * rnd + s, 32768, d, 80, 6))):
             full = batch.solve_batch(*args, sd0, sd1, variant=2, strict=True)
             for sound in (False, True):
                 got = batch.solve_batch(*args, sd0, sd1, variant=0 if sound else 3, sound=sound)
-                tally("solve 9-14 dof, %s%s" % (fam, ", sound" if sound else ""), 32768, differ(got, full, ("K", "sd2", "u", "status")))
+                tally("solve 9-15 dof, %s%s" % (fam, ", sound" if sound else ""), 32768, differ(got, full, ("K", "sd2", "u", "status")))
             Xf = batch.feasible_sets_batch(*args, variant=2, strict=True)
             for sound in (False, True):
-                tally("feasible sets 9-14 dof, %s%s" % (fam, ", sound" if sound else ""), 32768,
+                tally("feasible sets 9-15 dof, %s%s" % (fam, ", sound" if sound else ""), 32768,
                       differ({"X": batch.feasible_sets_batch(*args, variant=0 if sound else 3, sound=sound)}, {"X": Xf}, ("X",)))
             desired = rng.uniform(0.2, 8.0, size=32768)
-            tally("TOPPRAsd 9-14 dof, %s" % fam, 32768, differ(batch.solve_desired_duration_batch(*args, desired, sd0, sd1, variant=3),
+            tally("TOPPRAsd 9-15 dof, %s" % fam, 32768, differ(batch.solve_desired_duration_batch(*args, desired, sd0, sd1, variant=3),
                                                               batch.solve_desired_duration_batch(*args, desired, sd0, sd1, variant=2),
                                                               ("K", "sd2", "sd", "u", "status", "alpha")))
         print("round %d d=%d solve done" % (rnd, d), flush=True)

@@ -99,7 +99,7 @@ def solve_desired_duration_batch(coef, breaks, grid, vlim, alim, desired_duratio
 
     ``desired_duration``: scalar or [B] seconds.  Returns dict(sd2, sd, u, K, status, alpha): alpha is
     the blend between the fastest (1) and slowest (0) parameterizations found by bisection.
-    ``variant``: 0 = auto (from 9216 trajectories up to 8 dof, 14336 .. 34816 at 9 .. 14 dof: the certified lane kernel runs the backward scan and both
+    ``variant``: 0 = auto (from 9216 trajectories up to 8 dof, 14336 .. 36864 at 9 .. 15 dof: the certified lane kernel runs the backward scan and both
     forward profiles in one launch; rows across lanes otherwise), 2 / 3 force one.  ``squared``: sd_start / sd_end already
     hold sd^2 (TPR_BOUNDARY_SQUARED)."""
     _prepare(coef)

@@ -46,7 +46,7 @@ def stale():
 # per lane: 10.6 - 22 ms at 65536 x d x 200); the cause was one conditionally-needed load in CertStage::fetch that the compiler
 # sank into divergent regions (tpr_cert_lane.hip.inc), and without it they are back at 0 - 0.7 KB: 3.0 / 4.6 / 7.8 / 7.7 /
 # 10.9 ms at 9..13 dof against 10.2 - 12.0 for the rows-across-lanes kernels.
-CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "14"))
+CERT_MAX_DOF = int(os.environ.get("TPR_BUILD_CERT_MAX_DOF", "15"))
 CERT_DOFS = tuple(range(1, CERT_MAX_DOF + 1))
 
 
@@ -77,6 +77,10 @@ CERT_UNIT_PARTS = {
     12: {1: _TOPDOWN + _REVERSE, 2: _REVERSE, 3: _TOPDOWN},
     13: {1: _TOPDOWN + _REVERSE, 2: _TOPDOWN, 3: _TRACKERS + _REVERSE},
     14: {1: _TRACKERS + ["-fno-slp-vectorize"], 2: _TRACKERS + _REVERSE, 3: _TRACKERS},
+    # 15 dof (one 16-lane batch group: 40.5 KB of LDS): 9.6 / 10.3 / 12.1 ms against 13.9 for the rows-across-lanes solve.  As ONE unit
+    # this dof's TOPPRAsd kernel came out wrong (the allocator dropped a dword of a split register tuple:
+    # profiles/r06_dof15_unsplit_unit_incident.log); all thirty split builds of profiles/r06_dof15_parts.log pass both nets.
+    15: {1: _TRACKERS + _REVERSE, 2: _MAXILP, 3: _TRACKERS + ["-fno-slp-vectorize"]},
 }
 # ... and what the build tries next, in this order, when a unit's code shows a vector copy above an exec restore
 # (profiles/r06_miscompile_root_cause.md): the first clean code generation is linked, none is an error.

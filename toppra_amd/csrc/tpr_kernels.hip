@@ -24,9 +24,9 @@
 
 #define TPR_TU_CAT3_(a, b) a##b
 #define TPR_TU_CAT3(a, b) TPR_TU_CAT3_(a, b)
-// kernel family 3, one translation unit per dof (tpr_cert_tu.hip): 1..TPR_CERT_MAX_DOF (build.py: 14)
+// kernel family 3, one translation unit per dof (tpr_cert_tu.hip): 1..TPR_CERT_MAX_DOF (build.py: 15)
 #ifndef TPR_CERT_MAX_DOF
-#define TPR_CERT_MAX_DOF 14
+#define TPR_CERT_MAX_DOF 15
 #endif
 #ifdef TPR_SINGLE_TU  // development builds with instrumentation: everything in this translation unit, ONE dof for family 3 (7; -DTPR_SINGLE_TU_D=<dof>)
 #ifndef TPR_SINGLE_TU_D
@@ -591,7 +591,7 @@ int launch_pair(const tpr::BatchArgs &A, hipStream_t stream) {
 
 // Batch size from which family 3 is the automatic choice (solve, TOPPRAsd).
 // (measured against family 2, 9..14 dof: tools/gpu_crossover_slim.py, profiles/r06_crossover_9_14_dof.log)
-int cert_auto_from(int d) { return d <= 8 ? 9216 : (d <= 10 ? 14336 : (d == 11 ? 15360 : (d == 12 ? 17408 : (d == 13 ? 22528 : 34816)))); }
+int cert_auto_from(int d) { return d <= 8 ? 9216 : (d <= 10 ? 14336 : (d == 11 ? 15360 : (d == 12 ? 17408 : (d == 13 ? 22528 : (d == 14 ? 27648 : 36864))))); }
 
 // Kernel family of a solve (tpr_problem.variant 0 = auto).
 int pick_variant(int requested, const tpr::BatchArgs &A) {
@@ -632,7 +632,7 @@ int launch_solve(const tpr_problem *p, const tpr::BatchArgs &A, hipStream_t stre
         }
         case 3: {
             if (!cert_supported(A))
-                return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 14, sd2/u/status outputs, no strict mode");
+                return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 15, sd2/u/status outputs, no strict mode");
             return launch_cert(A, stream);
         }
         case 2: {
@@ -895,7 +895,7 @@ int tpr_solve_desired_duration_batch(const tpr_problem *p, const double *desired
         const bool fused = p->variant == 3 || (p->variant == 0 && cert_supported(Ab) && A.B >= cert_auto_from(A.d));
         if (fused) {
             // family 3: backward scan + fastest / slowest forward profiles in ONE launch (cert_solve_kernel<SDFWD>)
-            if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 14, no strict mode");
+            if (!cert_supported(Ab)) return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 15, no strict mode");
             if (int rc = launch_cert_sd(A, xf, uf, xl, ul, wdur, stream)) return rc;
             dur_in = wdur;
         } else {
@@ -1268,7 +1268,7 @@ int tpr_feasible_sets_batch(const tpr_problem *p, double *X, void *stream_) {
         const int want = p->variant;
         const bool wave_auto = wave_supported(A) && (A.active || A.B <= 64 || !group_supported(A));
         if (want == 3 && !cert_feasible_supported(A))
-            return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 14, no strict mode, no warm-start state");
+            return fail(TPR_E_UNSUPPORTED, "variant 3 needs an acceleration constraint, d <= 15, no strict mode, no warm-start state");
         if (want == 4 && !wave_supported(A)) return fail(TPR_E_UNSUPPORTED, "variant 4: N too large for the per-trajectory LDS tables");
         if (A.active && (want == 2 || want == 3))
             return fail(TPR_E_UNSUPPORTED, "tpr_problem.active (warm-start state in / out) is maintained by kernel families 4 and 1 only: leave variant at 0");
