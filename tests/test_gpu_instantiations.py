@@ -95,15 +95,21 @@ def _tight_joint_problem(d, seed):
 @pytest.mark.parametrize("d", range(1, 16))
 def test_every_joints_rows_bind_somewhere(gpu, oracle, d):
     data = _tight_joint_problem(d, 900 + d)
-    grid = data["grid"]
     desired = np.random.default_rng(50 + d).uniform(2.0, 40.0, size=4 * d)
-    for interp in (True, False):
+    rng = np.random.default_rng(60 + d)
+    inner = np.sort(rng.random((4 * d, N - 1)), axis=1) * 0.8 + 0.1
+    own_grids = 0.5 * np.concatenate([np.zeros((4 * d, 1)), inner, np.ones((4 * d, 1))], axis=1) + 0.5 * np.linspace(0, 1, N + 1)[None, :]
+    # every instantiation: grid shared (in LDS up to 8 dof) / per trajectory, Interpolation / Collocation, with / without the sd output
+    for grid, interp in ((data["grid"], True), (data["grid"], False), (own_grids, True), (own_grids, False)):
         args = (data["coef"], data["breaks"], grid, data["vlim"], data["alim"], None, None, interp)
         want = batch.solve_batch(*args, variant=2)
         got = batch.solve_batch(*args, variant=3)
+        got_sd = batch.solve_batch(*args, want_sd=True, variant=3)
+        for k in ("status", "K", "sd2", "u"):
+            assert np.array_equal(got_sd[k], want[k], equal_nan=True), (d, interp, grid.ndim, "family 3 with sd output", k)
         ref = oracle.solve_batch(data["coef"], data["breaks"], grid, data["vlim"], data["alim"], None, None,
                                  flags=oracle.DEFAULT_FLAGS if interp else oracle.DEFAULT_FLAGS & ~oracle.FLAG_INTERP, nthreads=4)
-        assert (ref["status"] == 0).mean() > 0.5, (d, interp)
+        assert (ref["status"] == 0).mean() > 0.5, (d, interp, grid.ndim)
         for k in ("status", "K", "sd2", "u"):
             assert np.array_equal(want[k], ref[k], equal_nan=True), (d, interp, "family 2 vs oracle", k)
             assert np.array_equal(got[k], ref[k], equal_nan=True), (d, interp, "family 3 vs oracle", k)
