@@ -111,12 +111,17 @@ def main(argv):
         from concurrent.futures import ThreadPoolExecutor
         sys.path.insert(0, ROOT)
         from toppra_amd import build as B
-        units = [("tpr_kernels.hip", ["-DTPR_CERT_MAX_DOF=%d" % B.CERT_MAX_DOF])]
-        units += [("tpr_cert_tu.hip", ["-DTPR_TU_D=%d" % d]) for d in B.CERT_DOFS]
-        units += [("tpr_robust_tu.hip", ["-DTPR_TU_HALF=%d" % h]) for h in (0, 1)] + [("tpr_dense_tu.hip", [])]
+        # (source, defines, the unit's own flags): family 3's units as build.py compiles them -- per-dof flags, split units
+        units = [("tpr_kernels.hip", ["-DTPR_CERT_MAX_DOF=%d" % B.CERT_MAX_DOF], [])]
+        for d in B.CERT_DOFS:
+            if d in B.CERT_UNIT_PARTS:
+                units += [("tpr_cert_tu.hip", ["-DTPR_TU_D=%d" % d, "-DTPR_TU_PART=%d" % part], list(fl)) for part, fl in sorted(B.CERT_UNIT_PARTS[d].items())]
+            else:
+                units.append(("tpr_cert_tu.hip", ["-DTPR_TU_D=%d" % d], list(B.CERT_UNIT_FLAGS.get(d, []))))
+        units += [("tpr_robust_tu.hip", ["-DTPR_TU_HALF=%d" % h], []) for h in (0, 1)] + [("tpr_dense_tu.hip", [], [])]
 
         def one(u):
-            p = tu_mir(0, argv[1:], source=u[0], defines=u[1])
+            p = tu_mir(0, list(u[2]) + argv[1:], source=u[0], defines=u[1])
             try:
                 nblk = sum(1 for l in open(p, errors="replace") if l.startswith("  bb."))
                 return u, scan_mir(p), nblk
@@ -124,7 +129,7 @@ def main(argv):
                 os.unlink(p)
         with ThreadPoolExecutor(max_workers=os.cpu_count() or 1) as pool:
             for u, h, nblk in pool.map(one, units):
-                print("%-20s %-22s %6d blocks  %d flagged" % (u[0], " ".join(u[1]), nblk, len(h)), flush=True)
+                print("%-20s %-34s %-70s %6d blocks  %d flagged" % (u[0], " ".join(u[1]), " ".join(u[2]), nblk, len(h)), flush=True)
                 hits += h
     else:
         print(__doc__)
